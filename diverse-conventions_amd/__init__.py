@@ -1,0 +1,17 @@
+"""MI355X-native Overcooked rollout engine behind the reference's vector-env API.
+
+    from diverse_conventions_amd import OvercookedMadrona, generate_env
+"""
+from .layouts import ALIASES, CLASSIC_LAYOUTS, get_base_layout_params, layout_names
+from .vectoragent import RandomVectorAgent, VectorAgent
+from .vectorenv import PlayerException, VectorMultiAgentEnv
+from .vectorobservation import VectorObservation
+from .engine import OvercookedEngine
+from .overcooked_env import OvercookedMadrona
+from .env_utils import generate_env
+
+__all__ = [
+    "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
+    "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "OvercookedMadrona",
+    "generate_env",
+]

@@ -1,0 +1,198 @@
+"""OvercookedEngine: thin Python owner of one native engine handle plus the torch tensors the
+kernels read and write.  PyTorch is plumbing here (device memory, streams); all simulation and
+featurisation happens in csrc/overcooked_engine.hip through the C ABI.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import native
+
+NUM_ACTIONS = 6
+CHANNELS = 20
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def pack_states(tiles, players, timestep, record_bytes):
+    """Fixture serialisation (tiles int8 [N,S,4], players int8 [N,2,6], timestep int32 [N]) ->
+    native state records uint32 [N, record_bytes/4] (layout: include/overcooked_hip.h)."""
+    tiles = np.ascontiguousarray(tiles, dtype=np.int8)
+    players = np.ascontiguousarray(players, dtype=np.int8)
+    n, s = tiles.shape[0], tiles.shape[1]
+    rec = np.zeros((n, record_bytes // 4), dtype=np.uint32)
+    rec[:, :s] = tiles.view(np.uint8).view("<u4").reshape(n, s)
+    pu = players.view(np.uint8).astype(np.uint32)
+    rec[:, s] = pu[:, 0, 0] | (pu[:, 0, 1] << 8) | (pu[:, 1, 0] << 16) | (pu[:, 1, 1] << 24)
+    for i in range(2):
+        rec[:, s + 1 + i] = pu[:, i, 2] | (pu[:, i, 3] << 8) | (pu[:, i, 4] << 16) | (pu[:, i, 5] << 24)
+    rec[:, s + 3] = np.asarray(timestep, dtype=np.int32).astype(np.uint32)
+    return rec
+
+
+def unpack_states(rec, s):
+    """Inverse of pack_states."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    n = rec.shape[0]
+    tiles = rec[:, :s].copy().view(np.uint8).reshape(n, s, 4).view(np.int8)
+    players = np.zeros((n, 2, 6), dtype=np.uint8)
+    posor = rec[:, s]
+    players[:, 0, 0] = posor & 0xFF
+    players[:, 0, 1] = (posor >> 8) & 0xFF
+    players[:, 1, 0] = (posor >> 16) & 0xFF
+    players[:, 1, 1] = (posor >> 24) & 0xFF
+    for i in range(2):
+        held = rec[:, s + 1 + i]
+        for b in range(4):
+            players[:, i, 2 + b] = (held >> (8 * b)) & 0xFF
+    return tiles, players.view(np.int8), rec[:, s + 3].astype(np.int32)
+
+
+class OvercookedEngine:
+    """N kitchens of one layout on one GPU.
+
+    Buffers (torch, on the engine's device; overwritten by every step):
+      obs    int8  [P, N, W, H, C]   reward int32 [P, N]   done int32 [N]
+    """
+
+    def __init__(self, params, num_kitchens, device_index=0):
+        self._handle = None
+        L = native.lib()                    # raises if the HIP library is not built
+        if not torch.cuda.is_available():
+            raise native.OvercookedNativeError(-4, "no GPU visible to PyTorch-ROCm; the engine has no CPU fallback")
+        self.params = dict(params)
+        self.num_kitchens = int(num_kitchens)
+        self.width, self.height = params["width"], params["height"]
+        self.size = self.width * self.height
+        self.num_players = params["num_players"]
+        self.device = torch.device("cuda", device_index)
+        handle = ctypes.c_void_p()
+        native.check(L.oc_create(ctypes.byref(native.make_params(params)), self.num_kitchens, device_index,
+                                 ctypes.byref(handle)))
+        self._handle = handle
+        self._L = L
+        self.record_bytes = int(L.oc_state_record_bytes(handle))
+        n = self.num_kitchens
+        with torch.cuda.device(self.device):
+            self.obs = torch.zeros((2, n, self.width, self.height, CHANNELS), dtype=torch.int8, device=self.device)
+            self.reward = torch.zeros((2, n), dtype=torch.int32, device=self.device)
+            self.done = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self.observe()
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if self._handle is not None:
+            torch.cuda.synchronize(self.device)
+            self._L.oc_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ hot path
+    def _actions(self, actions):
+        a = actions
+        if a.device != self.device:
+            a = a.to(self.device)
+        if a.dtype not in (torch.int32, torch.int64):
+            a = a.to(torch.int32)
+        if a.numel() != 2 * self.num_kitchens:
+            raise ValueError(f"actions must have {2 * self.num_kitchens} elements ([P, N] or [P, N, 1]), got {tuple(a.shape)}")
+        if not a.is_contiguous():
+            a = a.contiguous()
+        return a, (native.OC_ACT_I64 if a.dtype == torch.int64 else native.OC_ACT_I32)
+
+    def step(self, actions, obs=None, reward=None, done=None):
+        """One fused transition+featurisation launch on the current torch stream (no host sync).
+        actions: int32/int64 [P, N] or [P, N, 1].  Outputs go to the engine's own buffers unless
+        explicit destination tensors (same shapes/dtypes) are given."""
+        a, dt = self._actions(actions)
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        done = self.done if done is None else done
+        native.check(self._L.oc_step(self._handle, _ptr(a), dt, _ptr(obs), _ptr(reward), _ptr(done), self._stream()))
+        return obs, reward, done
+
+    def observe(self, obs=None):
+        obs = self.obs if obs is None else obs
+        native.check(self._L.oc_observe(self._handle, _ptr(obs), self._stream()))
+        return obs
+
+    def reset_all(self, obs=None):
+        obs = self.obs if obs is None else obs
+        native.check(self._L.oc_reset_all(self._handle, _ptr(obs), self._stream()))
+        return obs
+
+    def rollout(self, actions, steps, obs=None, reward=None, done=None):
+        """`steps` consecutive launches enqueued from C.  actions [T_act, P, N] are cycled.
+        obs/reward/done may carry a leading time axis of length `steps` (time-major trajectory
+        buffers, written in place) or be single-step buffers that are overwritten."""
+        if actions.dim() < 3:
+            raise ValueError("rollout actions must be [T_act, P, N]")
+        t_act = actions.shape[0]
+        a, dt = self._actions(actions.reshape(-1)[: 2 * self.num_kitchens].view(2, self.num_kitchens))
+        flat = actions if actions.is_contiguous() else actions.contiguous()
+        if flat.device != self.device or flat.dtype not in (torch.int32, torch.int64):
+            flat = flat.to(device=self.device, dtype=torch.int32)
+            dt = native.OC_ACT_I32
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        done = self.done if done is None else done
+        so = obs[0].numel() if obs.dim() == 6 else 0
+        sr = reward[0].numel() if reward.dim() == 3 else 0
+        sd = done[0].numel() if done.dim() == 2 else 0
+        native.check(self._L.oc_rollout(self._handle, _ptr(flat), dt, t_act, steps, _ptr(obs), so, _ptr(reward), sr,
+                                        _ptr(done), sd, self._stream()))
+        return obs, reward, done
+
+    def rollout_timed(self, actions, steps):
+        """-> milliseconds between hipEvents bracketing `steps` step launches (synchronises)."""
+        flat = actions.contiguous()
+        dt = native.OC_ACT_I64 if flat.dtype == torch.int64 else native.OC_ACT_I32
+        ms = ctypes.c_float()
+        native.check(self._L.oc_rollout_timed(self._handle, _ptr(flat), dt, actions.shape[0], steps, _ptr(self.obs),
+                                              _ptr(self.reward), _ptr(self.done), self._stream(), ctypes.byref(ms)))
+        return ms.value
+
+    def encode_states(self, records, obs=None):
+        """records: uint8/int32 device tensor holding n native state records -> int8 [P, n, W, H, C]."""
+        n = records.numel() * records.element_size() // self.record_bytes
+        if obs is None:
+            obs = torch.empty((2, n, self.width, self.height, CHANNELS), dtype=torch.int8, device=self.device)
+        native.check(self._L.oc_encode_states(self._handle, _ptr(records), n, _ptr(obs), self._stream()))
+        return obs
+
+    def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0):
+        native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush))
+
+    # ------------------------------------------------------------------ state import/export
+    def export_states(self, first=0, count=None, out=None):
+        count = self.num_kitchens - first if count is None else count
+        if out is None:
+            out = torch.empty((count, self.record_bytes // 4), dtype=torch.int32, device=self.device)
+        native.check(self._L.oc_export_states(self._handle, first, count, _ptr(out), self._stream()))
+        return out
+
+    def import_states(self, records, first=0):
+        count = records.numel() * records.element_size() // self.record_bytes
+        native.check(self._L.oc_import_states(self._handle, first, count, _ptr(records), self._stream()))
+
+    def get_state(self, first=0, count=None):
+        """-> (tiles int8 [n,S,4], players int8 [n,2,6], timestep int32 [n]); synchronises."""
+        count = self.num_kitchens - first if count is None else count
+        rec = np.empty((count, self.record_bytes // 4), dtype=np.uint32)
+        native.check(self._L.oc_get_state(self._handle, first, count, rec.ctypes.data_as(ctypes.c_void_p)))
+        return unpack_states(rec, self.size)
+
+    def set_state(self, tiles, players, timestep, first=0):
+        rec = pack_states(tiles, players, timestep, self.record_bytes)
+        native.check(self._L.oc_set_state(self._handle, first, rec.shape[0], rec.ctypes.data_as(ctypes.c_void_p)))

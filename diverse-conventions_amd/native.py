@@ -1,0 +1,128 @@
+"""ctypes binding of the C ABI in include/overcooked_hip.h (library: csrc/liboc_hip.so).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is no
+Python or CPU fallback for the hot path (the CPU oracle under oracle/ is test infrastructure).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
+SOURCES = [os.path.join(CSRC, "overcooked_engine.hip")]
+INCLUDE = os.path.join(REPO_ROOT, "include")
+
+OC_OK = 0
+OC_ACT_I32, OC_ACT_I64 = 0, 1
+STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", -3: "OC_ERR_HIP", -4: "OC_ERR_NO_DEVICE"}
+
+# every symbol include/overcooked_hip.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = [
+    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_rollout", "oc_rollout_timed",
+    "oc_encode_states", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
+    "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
+    "oc_last_error", "oc_abi_version",
+]
+
+
+class OcLayoutParams(ctypes.Structure):
+    """struct oc_layout_params"""
+    _fields_ = [
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("num_players", ctypes.c_int32),
+        ("placement_in_pot_rew", ctypes.c_int32), ("dish_pickup_rew", ctypes.c_int32),
+        ("soup_pickup_rew", ctypes.c_int32), ("horizon", ctypes.c_int32),
+        ("recipe_values", ctypes.c_int32 * 16), ("recipe_times", ctypes.c_int32 * 16),
+        ("start_player_x", ctypes.c_int32 * 2), ("start_player_y", ctypes.c_int32 * 2),
+        ("terrain", ctypes.c_int32 * 256),
+    ]
+
+
+class OvercookedNativeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
+    newest = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "overcooked_hip.h")])
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE,
+           "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    L.oc_create.argtypes = [ctypes.POINTER(OcLayoutParams), i64, i32, ctypes.POINTER(vp)]
+    L.oc_destroy.argtypes = [vp]
+    L.oc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.oc_observe.argtypes = [vp, vp, vp]
+    L.oc_reset_all.argtypes = [vp, vp, vp]
+    L.oc_rollout.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, i64, vp]
+    L.oc_rollout_timed.argtypes = [vp, vp, i32, i64, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.oc_encode_states.argtypes = [vp, vp, i64, vp, vp]
+    L.oc_state_record_bytes.argtypes = [vp]
+    L.oc_state_record_bytes.restype = i64
+    L.oc_get_state.argtypes = [vp, i64, i64, vp]
+    L.oc_set_state.argtypes = [vp, i64, i64, vp]
+    L.oc_export_states.argtypes = [vp, i64, i64, vp, vp]
+    L.oc_import_states.argtypes = [vp, i64, i64, vp, vp]
+    L.oc_num_kitchens.argtypes = [vp]
+    L.oc_num_kitchens.restype = i64
+    L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
+    L.oc_device_id.argtypes = [vp]
+    L.oc_set_tuning.argtypes = [vp, i32, i32]
+    L.oc_last_error.argtypes = []
+    L.oc_last_error.restype = ctypes.c_char_p
+    L.oc_abi_version.argtypes = []
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int:          # default restype: int status
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OC_OK:
+        raise OvercookedNativeError(status, lib().oc_last_error().decode())
+
+
+def make_params(params):
+    """dict from get_base_layout_params -> struct oc_layout_params"""
+    if params["num_players"] > 2:
+        raise OvercookedNativeError(-2, f"only 2-player kitchens are supported (got {params['num_players']})")
+    S = params["width"] * params["height"]
+    if S > 255 or len(params["terrain"]) != S:
+        raise OvercookedNativeError(-2, f"grid {params['width']}x{params['height']} outside 1..255 tiles")
+    p = OcLayoutParams()
+    for k in ("width", "height", "num_players", "placement_in_pot_rew", "dish_pickup_rew", "soup_pickup_rew", "horizon"):
+        setattr(p, k, int(params[k]))
+    for i in range(16):
+        p.recipe_values[i] = int(params["recipe_values"][i])
+        p.recipe_times[i] = int(params["recipe_times"][i])
+    for i in range(params["num_players"]):
+        p.start_player_x[i] = int(params["start_player_x"][i])
+        p.start_player_y[i] = int(params["start_player_y"][i])
+    for i, t in enumerate(params["terrain"]):
+        p.terrain[i] = int(t)
+    return p

@@ -1,0 +1,142 @@
+/*
+ * overcooked_hip.h -- C ABI of the MI355X-native Overcooked rollout engine.
+ *
+ * This is the drop-in boundary for the reference's native simulator binding
+ * (Simplecooked "SimplecookedSimulator", /root/reference/src/overcooked2_env/bindings.cpp:27-96,
+ * Manager in mgr.hpp:14-67 / mgr.cpp:128-272).  The reference exports a constructor taking the
+ * flat layout parameters, a blocking step(), and ten zero-copy tensors; this ABI exports the same
+ * capability as plain C: a handle that owns the per-kitchen state in HBM, a stream-ordered step()
+ * that reads an action buffer and writes observation / reward / done buffers (device pointers
+ * supplied by the caller -- torch tensors on the Python side), plus state import/export for tests,
+ * checkpoints and trajectory exchange.
+ *
+ * Conventions
+ *   - every entry point returns OC_OK (0) or a negative oc_status; oc_last_error() gives the text
+ *     (thread-local).  No exceptions cross the boundary, nothing aborts the process.
+ *   - all pointers named d_* are DEVICE pointers on the engine's GPU; `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).  Calls only enqueue work: no implicit
+ *     device synchronisation except in oc_create / oc_destroy / oc_get_state / oc_set_state.
+ *   - one handle = one GPU = one caller thread at a time (same contract as the reference,
+ *     SURVEY.md 8(b) "threading").  Several handles per process are fine.
+ *   - P = 2 players (the reference's encoder and dish-usefulness rule are 2-player; other player
+ *     counts return OC_ERR_UNSUPPORTED), S = width*height <= 255 tiles, C = 5P+10 = 20 channels.
+ *
+ * Tensor layouts (identical in meaning to the reference's exported tensors)
+ *   actions  int32 or int64 [P][N]        ref: action_tensor   i32[P,N,1]   (mgr.cpp:225-229)
+ *   obs      int8  [P][N][W][H][C]        ref: observation_tensor after the (P,H,W,N,C)->transpose(1,3)
+ *                                              view of envs/overcooked2_env.py:103-114
+ *   reward   int32 [P][N]  (sum over players, replicated)  ref: reward_tensor (sim.cpp:623)
+ *   done     int32 [N]     1 on the step whose timestep reached the horizon; the kitchen is
+ *                          reset inside that step and obs is the reset observation
+ *                          ref: done_tensor / WorldReset (sim.cpp:592-640)
+ *
+ * State record (oc_get_state / oc_set_state / oc_export_states / oc_encode_states), little endian,
+ * oc_state_record_bytes() bytes per kitchen = 16 * ceil((S + 4) / 4):
+ *   uint32 tile[S]     name | onions<<8 | tomatoes<<16 | (uint8)cooking_tick<<24   (0 = empty)
+ *   uint32 posor       p0.pos | p0.orient<<8 | p1.pos<<16 | p1.orient<<24
+ *   uint32 held[2]     same packing as a tile object
+ *   uint32 timestep
+ *   zero padding to a multiple of 16 bytes
+ */
+#ifndef OVERCOOKED_HIP_H
+#define OVERCOOKED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OC_MAX_TILES 255
+#define OC_MAX_PLAYERS 2
+#define OC_NUM_ACTIONS 6
+#define OC_ABI_VERSION 1
+
+typedef enum {
+    OC_OK = 0,
+    OC_ERR_INVALID_ARG = -1,   /* NULL pointer, bad size, misaligned buffer, terrain code out of range ... */
+    OC_ERR_UNSUPPORTED = -2,   /* num_players != 2, too many tiles/pots, cook time > 127 */
+    OC_ERR_HIP = -3,           /* a HIP runtime call failed; text in oc_last_error() */
+    OC_ERR_NO_DEVICE = -4      /* no usable GPU: the engine never falls back to the CPU */
+} oc_status;
+
+typedef enum { OC_ACT_I32 = 0, OC_ACT_I64 = 1 } oc_action_dtype;
+
+/* Flat layout parameters: field for field the keyword arguments of the reference constructor
+ * (bindings.cpp:28-84; produced in Python by get_base_layout_params, envs/overcooked2_env.py:171-291). */
+typedef struct {
+    int32_t width, height, num_players;
+    int32_t placement_in_pot_rew, dish_pickup_rew, soup_pickup_rew;
+    int32_t horizon;
+    int32_t recipe_values[16];          /* index 4*onions + tomatoes */
+    int32_t recipe_times[16];
+    int32_t start_player_x[OC_MAX_PLAYERS];
+    int32_t start_player_y[OC_MAX_PLAYERS];
+    int32_t terrain[256];               /* row-major, terrain[y*width+x], codes 0..6 */
+} oc_layout_params;
+
+typedef struct oc_engine oc_engine;
+
+/* replaces Manager::Manager(Config) (mgr.cpp:179-206) / SimplecookedSimulator.__init__.
+ * Allocates the state block for n_kitchens kitchens on device_id and puts every kitchen in the
+ * standard start state (ref envs/overcooked2_reimplement.py:387-391). */
+int oc_create(const oc_layout_params *params, int64_t n_kitchens, int device_id, oc_engine **out);
+
+/* replaces Manager::~Manager (mgr.cpp:206) */
+int oc_destroy(oc_engine *e);
+
+/* replaces Manager::step (mgr.cpp:208-211), but stream-ordered instead of blocking.
+ * One fused launch: joint interact/move/collision transition, pot timers, horizon auto-reset,
+ * reward, done, and the 20-channel lossless_state_encoding of the post-step state for both viewers. */
+int oc_step(oc_engine *e, const void *d_actions, int action_dtype, int8_t *d_obs, int32_t *d_reward,
+            int32_t *d_done, void *stream);
+
+/* Observation of the current state without stepping: what OvercookedMadrona.n_reset()/get_obs()
+ * return (envs/overcooked2_env.py:103-114,127-128 -- n_reset re-reads, it does not reset). */
+int oc_observe(oc_engine *e, int8_t *d_obs, void *stream);
+
+/* Put every kitchen back in the start state (what constructing a fresh simulator does,
+ * sim.cpp:690-704 resetWorld) and, if d_obs != NULL, write the start observation. */
+int oc_reset_all(oc_engine *e, int8_t *d_obs, void *stream);
+
+/* T consecutive steps enqueued from C (no host work between launches): actions [T_act][P][N] are
+ * consumed cyclically (step t uses slice t % T_act); obs/reward/done are overwritten every step
+ * unless the *_step_stride (in elements, may be 0) says to advance per step.  Rollout driver for
+ * bench.py and for trajectory collection straight into time-major buffers. */
+int oc_rollout(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T,
+               int8_t *d_obs, int64_t obs_step_stride, int32_t *d_reward, int64_t reward_step_stride,
+               int32_t *d_done, int64_t done_step_stride, void *stream);
+
+/* Same as oc_rollout but brackets the T launches with hipEvents on `stream`, synchronises, and
+ * returns the elapsed milliseconds (kernel-time basis for the roofline figure). */
+int oc_rollout_timed(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T,
+                     int8_t *d_obs, int32_t *d_reward, int32_t *d_done, void *stream, float *elapsed_ms);
+
+/* Featurise n externally supplied state records (device pointer, record format above) without
+ * touching the engine's own kitchens: the receive side of a compact trajectory exchange. */
+int oc_encode_states(oc_engine *e, const void *d_states, int64_t n, int8_t *d_obs, void *stream);
+
+/* State import / export.  get/set are synchronous host copies (tests, checkpoints);
+ * export/import are stream-ordered device-to-device copies of `count` records starting at `first`. */
+int64_t oc_state_record_bytes(const oc_engine *e);
+int oc_get_state(oc_engine *e, int64_t first, int64_t count, void *host_dst);
+int oc_set_state(oc_engine *e, int64_t first, int64_t count, const void *host_src);
+int oc_export_states(oc_engine *e, int64_t first, int64_t count, void *d_dst, void *stream);
+int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_src, void *stream);
+
+/* Introspection */
+int64_t oc_num_kitchens(const oc_engine *e);
+int oc_obs_shape(const oc_engine *e, int64_t shape5[5]);   /* P, N, W, H, C */
+int oc_device_id(const oc_engine *e);
+
+/* Launch tuning (performance only, results never change): kitchens per wavefront (4..64, multiple
+ * of 4) and staging passes per flush (1..8).  0 keeps the current value. */
+int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush);
+
+const char *oc_last_error(void);
+int oc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVERCOOKED_HIP_H */

@@ -1,0 +1,59 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def load_golden(path):
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_layout_of(path, rec):
+    if "layout" in rec:
+        return str(rec["layout"])
+    base = os.path.basename(path)[:-4]
+    for prefix in ("random_", "guided_"):
+        if base.startswith(prefix):
+            return base[len(prefix):]
+    if base == "scripted_recipe_simple":
+        return "simple"
+    raise KeyError(path)
+
+
+@pytest.fixture(scope="session")
+def layout_params():
+    with open(os.path.join(GOLDEN, "layout_params.json")) as f:
+        return json.load(f)
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected explicitly with -m gpu; skip them when no GPU is visible so a bare
+    # `pytest tests` still passes in the CPU container.
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,89 @@
+"""Pins the CPU oracle (oracle/overcooked_oracle.c) to the reference: every committed fixture in
+tests/golden/ (generated from the reference Python by tests/golden/make_golden.py) must be reproduced
+bit for bit -- states, per-player rewards, dones, observations -- plus the SHA-256 stream hashes
+SURVEY.md 8(c) records."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_files, golden_layout_of, load_golden
+from oracle import oracle
+
+ALL = golden_files("random_") + golden_files("guided_") + golden_files("micro_") + golden_files("scripted_")
+
+
+@pytest.mark.parametrize("path", ALL, ids=[os.path.basename(p)[:-4] for p in ALL])
+def test_oracle_replays_fixture(path, layout_params):
+    rec = load_golden(path)
+    params = layout_params[golden_layout_of(path, rec)]
+    env = oracle.OracleVecEnv(params, 1)
+    env.set_state(rec["init_tiles"][None], rec["init_players"][None], rec["init_timestep"][None])
+    assert np.array_equal(env.encode()[:, 0], rec["init_obs"])
+    tiles, players, ts = rec["init_tiles"], rec["init_players"], int(rec["init_timestep"])
+    for t, a in enumerate(rec["actions"]):
+        # raw MDP transition: per-player rewards, before the wrapper sums / resets
+        nt, npl, nts, r = oracle.transition(params, tiles, players, ts, a)
+        assert np.array_equal(r, rec["reward_per_player"][t]), f"step {t}: per-player reward"
+        obs, reward, done = env.step(a.reshape(-1, 1))
+        assert int(done[0]) == int(rec["done"][t]), f"step {t}: done"
+        assert np.all(reward[:, 0] == rec["reward"][t]), f"step {t}: reward"
+        tiles, players, ts = (x[0] for x in env.get_state())
+        ts = int(ts)
+        if not done[0]:
+            assert np.array_equal(nt, tiles) and np.array_equal(npl, players) and nts == ts
+        assert np.array_equal(tiles, rec["tiles"][t]), f"step {t}: tiles"
+        assert np.array_equal(players, rec["players"][t]), f"step {t}: players"
+        assert ts == int(rec["timestep"][t]), f"step {t}: timestep"
+        assert np.array_equal(obs[:, 0], rec["obs"][t]), f"step {t}: obs"
+
+
+def test_oracle_stream_hashes(layout_params):
+    """sha256 over [start obs] + sum_t [obs_t | i32 reward | u8 done], 1000 random steps."""
+    with open(os.path.join(GOLDEN, "random_rollout_sha256.json")) as f:
+        want = json.load(f)
+    survey = {"simple": "60d3ae283cb9cd198009eff92eea89e8", "unident_s": "807c03d77cc971dbac3451ae9a22e196",
+              "random1": "04c72b39f2ad59c2b326cfe846bc6330", "random0": "adedfdde670becf6719854228b9e7b69",
+              "random3": "479c6f1ddcb0fa1c6ffaac73f06e4a96"}
+    for name, digest in survey.items():
+        assert want[name] == digest
+    for name, digest in want.items():
+        params = layout_params[name]
+        env = oracle.OracleVecEnv(params, 1)
+        rng = np.random.default_rng(0)
+        h = hashlib.sha256()
+        h.update(env.encode()[:, 0].tobytes())
+        for _ in range(1000):
+            a = rng.integers(0, 6, size=params["num_players"])
+            obs, rew, done = env.step(a.reshape(-1, 1))
+            h.update(np.ascontiguousarray(obs[:, 0]).tobytes())
+            h.update(np.int32(rew[0, 0]).tobytes())
+            h.update(np.uint8(done[0]).tobytes())
+        assert h.hexdigest()[:32] == digest, name
+
+
+def test_oracle_matches_syncvectorenv_batch(layout_params):
+    """The batched surface: reference SyncVectorEnv over 3 envs, 420 steps (two horizon resets)."""
+    rec = load_golden(os.path.join(GOLDEN, "syncvec_simple.npz"))
+    env = oracle.OracleVecEnv(layout_params["simple"], 3)
+    assert np.array_equal(env.encode(), rec["init_obs"])
+    for t in range(rec["actions"].shape[0]):
+        obs, rew, done = env.step(rec["actions"][t])
+        assert np.array_equal(obs, rec["obs"][t]), t
+        assert np.array_equal(rew, rec["reward"][t]), t
+        assert np.array_equal(done.astype(np.uint8), rec["done"][t]), t
+    assert rec["done"].sum() == 6
+
+
+def test_oracle_threads_agree(layout_params):
+    params = layout_params["unident_s"]
+    a = oracle.OracleVecEnv(params, 257, nthreads=1)
+    b = oracle.OracleVecEnv(params, 257, nthreads=4)
+    rng = np.random.default_rng(3)
+    for _ in range(250):
+        act = rng.integers(0, 6, size=(2, 257))
+        oa, ra, da = a.step(act)
+        ob, rb, db = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
