@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: agent-env steps/s of the fused step+encode path (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One rank per GPU, each owning `--kitchens` kitchens (weak scaling: kitchens are independent, the
+rollout has no data-path collective).  A step = one launch of the fused kernel over every kitchen of
+the rank with synthetic uniform-random joint actions already resident in HBM.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(S, P=2):
+    """bytes one kitchen-step must move.  obs i8 write + state read&write
+    (4 B/tile + 6 B/player + 4 B timestep) + i32 actions read + i32 rewards write + i32 done write."""
+    return P * S * (5 * P + 10) + 2 * (4 * S + 6 * P + 4) + 4 * P + 4 * P + 4
+
+
+def cpu_baseline(params, kitchens, budget_s=12.0):
+    """Oracle (CPU port of the reference algorithm) on the same workload, bounded sample."""
+    import numpy as np
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    env = oracle.OracleVecEnv(params, kitchens, nthreads=cores)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 6, size=(8, 2, kitchens)).astype(np.int32)
+    env.step(acts[0])                                    # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        env.step(acts[steps % 8])
+        steps += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and steps >= 8) or steps >= 2000:
+            break
+    multi = 2 * kitchens * steps / el
+    # single-core figure on a smaller slice of the same workload
+    env1 = oracle.OracleVecEnv(params, 4096, nthreads=1)
+    a1 = acts[:, :, :4096].copy()
+    env1.step(a1[0])
+    t0 = time.perf_counter()
+    s1 = 0
+    while time.perf_counter() - t0 < 3.0:
+        env1.step(a1[s1 % 8]); s1 += 1
+    single = 2 * 4096 * s1 / (time.perf_counter() - t0)
+    return {"value": multi, "unit": "agent-env steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {kitchens} kitchens, same layout/actions law, OpenMP over kitchens "
+                      f"({el:.1f} s); 1-core: {single:.0f} steps/s on 4096 kitchens",
+            "value_1core": single,
+            "reference_python_survey_container": {"value": 64000, "cores": 1,
+                                                  "note": "reference SimplifiedOvercooked.n_step, BASELINE.md section 2 (other host)"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--kitchens", type=int, default=65536, help="kitchens per GPU")
+    ap.add_argument("--layout", default="cramped_room")
+    ap.add_argument("--kpw", type=int, default=0, help="kitchens per wave (0 = engine default)")
+    ap.add_argument("--passes", type=int, default=0, help="staging passes per flush (0 = engine default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    params = get_base_layout_params(args.layout, 200)
+    S = params["width"] * params["height"]
+    n = args.kitchens
+    eng = OvercookedEngine(params, n, local)
+    if args.kpw or args.passes:
+        eng.set_tuning(args.kpw, args.passes)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    t_act = 64
+    actions = torch.randint(0, 6, (t_act, 2, n), generator=gen, device="cuda", dtype=torch.int32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.rollout(actions, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
+    barrier()
+    wall = time.perf_counter() - t0
+    stats = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    wall, kernel_ms = float(stats[0]), float(stats[1])
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes(S) * n
+        per_launch_s = kernel_ms / 1e3 / args.steps
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            key = f"{args.layout}:{n}"
+            traffic = tj.get(key, {}).get("bytes_per_launch")
+        out = {
+            "metric": "agent-env steps/sec at 64k parallel kitchens, 1/2/4/8 MI355X",
+            "value": 2 * n * world * args.steps / wall,
+            "unit": "agent-env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.layout}, {n} kitchens per GPU, 2 agents, uniform random joint actions "
+                                   f"(i32, resident in HBM), horizon 200 with in-step auto-reset, fused step+encode, "
+                                   f"one launch per step",
+                       "layout": args.layout, "kitchens_per_gpu": n, "parallelism": f"kitchen-shard x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "oc_step_kernel<STEP,i32,vec16>", "bytes_per_launch": bytes_per_launch,
+                         "us_per_launch": per_launch_s * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, n)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,14 +136,14 @@ class OvercookedEngine:
         """`steps` consecutive launches enqueued from C.  actions [T_act, P, N] are cycled.
         obs/reward/done may carry a leading time axis of length `steps` (time-major trajectory
         buffers, written in place) or be single-step buffers that are overwritten."""
-        if actions.dim() < 3:
-            raise ValueError("rollout actions must be [T_act, P, N]")
+        if actions.dim() < 3 or actions[0].numel() != 2 * self.num_kitchens:
+            raise ValueError(f"rollout actions must be [T_act, P, N] with P*N = {2 * self.num_kitchens}")
         t_act = actions.shape[0]
-        a, dt = self._actions(actions.reshape(-1)[: 2 * self.num_kitchens].view(2, self.num_kitchens))
-        flat = actions if actions.is_contiguous() else actions.contiguous()
-        if flat.device != self.device or flat.dtype not in (torch.int32, torch.int64):
-            flat = flat.to(device=self.device, dtype=torch.int32)
-            dt = native.OC_ACT_I32
+        flat = actions if actions.device == self.device else actions.to(self.device)
+        if flat.dtype not in (torch.int32, torch.int64):
+            flat = flat.to(torch.int32)
+        flat = flat.contiguous()
+        dt = native.OC_ACT_I64 if flat.dtype == torch.int64 else native.OC_ACT_I32
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
         done = self.done if done is None else done

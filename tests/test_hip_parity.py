@@ -1,0 +1,232 @@
+"""Parity tests proper: the HIP engine, called through the C ABI, against (a) the committed golden
+fixtures generated from the reference Python and (b) the CPU oracle on seeded action streams.
+Bar: bit-exact (integer / byte work).  All tests need a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files, golden_layout_of, load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+TWO_PLAYER = lambda p: p["num_players"] == 2
+FIXTURES = golden_files("random_") + golden_files("guided_") + golden_files("micro_") + golden_files("scripted_")
+
+
+def _engine(params, n):
+    from diverse_conventions_amd import OvercookedEngine
+    return OvercookedEngine(params, n, 0)
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_hip_replays_reference_fixture(path, layout_params):
+    """HIP engine vs outputs recorded from the reference itself: obs, reward, done, full state, every step."""
+    rec = load_golden(path)
+    params = layout_params[golden_layout_of(path, rec)]
+    eng = _engine(params, 1)
+    eng.set_state(rec["init_tiles"][None], rec["init_players"][None], rec["init_timestep"][None])
+    assert np.array_equal(eng.observe().cpu().numpy()[:, 0], rec["init_obs"])
+    T = len(rec["actions"])
+    acts = torch.from_numpy(rec["actions"].astype(np.int32)).cuda().reshape(T, 2, 1)
+    for t in range(T):
+        obs, rew, done = eng.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy()[:, 0], rec["obs"][t]), f"step {t}: obs"
+        assert np.all(rew.cpu().numpy()[:, 0] == rec["reward"][t]), f"step {t}: reward"
+        assert int(done.cpu()[0]) == int(rec["done"][t]), f"step {t}: done"
+        tiles, players, ts = eng.get_state()
+        assert np.array_equal(tiles[0], rec["tiles"][t]), f"step {t}: tiles"
+        assert np.array_equal(players[0], rec["players"][t]), f"step {t}: players"
+        assert int(ts[0]) == int(rec["timestep"][t]), f"step {t}: timestep"
+    eng.close()
+
+
+def _mixed_actions(layout, T, n, seed, p_guided=0.85):
+    """Per-kitchen action streams: the fixture's guided stream (which cooks and delivers) with
+    per-kitchen random substitutions, so kitchens diverge but keep doing useful work."""
+    g = load_golden(os.path.join(GOLDEN, f"guided_{layout}.npz"))["actions"]
+    rng = np.random.default_rng(seed)
+    base = np.broadcast_to(g[:T, :, None], (T, 2, n))
+    rnd = rng.integers(0, 6, size=(T, 2, n))
+    keep = rng.random((T, 1, n)) < p_guided
+    return np.where(keep, base, rnd).astype(np.int32)
+
+
+@pytest.mark.parametrize("layout", ["simple", "unident_s", "random1", "random0", "random3", "mdp_test",
+                                    "simple_tomato", "corridor", "scenario2_s"])
+def test_hip_vs_oracle_batch(layout, layout_params):
+    """4099 kitchens (ragged last wave), 450 steps crossing two horizon resets."""
+    params = layout_params[layout]
+    n, T = 4099, 450
+    acts = _mixed_actions(layout, T, n, seed=11)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng = _engine(params, n)
+    assert np.array_equal(eng.observe().cpu().numpy(), ora.encode())
+    dacts = torch.from_numpy(acts).cuda()
+    total = 0
+    for t in range(T):
+        obs, rew, done = eng.step(dacts[t])
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(rew.cpu().numpy(), orew), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), odone), f"step {t}: done"
+        assert np.array_equal(obs.cpu().numpy(), oobs), f"step {t}: obs"
+        total += int(orew[0].sum())
+        if t % 50 == 49 or t == T - 1:
+            for x, y in zip(eng.get_state(), ora.get_state()):
+                assert np.array_equal(x, y), f"step {t}: state"
+    assert total > 0          # the streams really cook and deliver
+    eng.close()
+
+
+@pytest.mark.parametrize("kpw,passes", [(4, 1), (8, 2), (16, 4), (32, 8), (64, 3), (12, 5)])
+def test_tuning_does_not_change_results(kpw, passes, layout_params):
+    params = layout_params["random1"]            # S = 25: odd record padding, non-16B kitchen planes
+    n, T = 1003, 230
+    acts = _mixed_actions("random1", T, n, seed=5)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng = _engine(params, n)
+    eng.set_tuning(kpw, passes)
+    dacts = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        obs, rew, done = eng.step(dacts[t])
+        oobs, orew, odone = ora.step(acts[t])
+        if t % 23 == 0 or t >= 198:
+            assert np.array_equal(obs.cpu().numpy(), oobs), t
+            assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone), t
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 63, 64, 65])
+def test_small_and_ragged_sizes(n, layout_params):
+    for layout in ("simple", "random0", "unident_s"):
+        params = layout_params[layout]
+        acts = _mixed_actions(layout, 210, n, seed=n)
+        ora = oracle.OracleVecEnv(params, n)
+        eng = _engine(params, n)
+        dacts = torch.from_numpy(acts).cuda()
+        for t in range(210):
+            obs, rew, done = eng.step(dacts[t])
+            oobs, orew, odone = ora.step(acts[t])
+            assert np.array_equal(obs.cpu().numpy(), oobs), (layout, t)
+            assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone)
+        eng.close()
+
+
+def test_unaligned_destination_and_int64_actions(layout_params):
+    """obs written into a caller buffer that is only 4-byte aligned (dword store path), actions as
+    int64 [P, N, 1] exactly as torch.stack of sampled actions gives them."""
+    params = layout_params["simple"]
+    n, T = 515, 60
+    acts = _mixed_actions("simple", T, n, seed=2)
+    ora = oracle.OracleVecEnv(params, n)
+    eng = _engine(params, n)
+    raw = torch.zeros(eng.obs.numel() + 64, dtype=torch.int8, device="cuda")
+    view = raw[4:4 + eng.obs.numel()].view(eng.obs.shape)
+    assert view.data_ptr() % 16 == 4
+    for t in range(T):
+        a64 = torch.from_numpy(acts[t]).cuda().to(torch.int64).unsqueeze(-1)
+        obs, rew, done = eng.step(a64, obs=view)
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(rew.cpu().numpy(), orew)
+    assert int(raw[:4].abs().sum()) == 0 and int(raw[4 + eng.obs.numel():].abs().sum()) == 0   # no stray writes
+    eng.close()
+
+
+def test_out_of_range_action_is_stay(layout_params):
+    params = layout_params["simple"]
+    eng = _engine(params, 4)
+    ora = oracle.OracleVecEnv(params, 4)
+    bad = torch.tensor([[7, -1, 6, 100], [2, 3, -5, 9]], dtype=torch.int32, device="cuda")
+    ok = np.array([[4, 4, 4, 4], [2, 3, 4, 4]], dtype=np.int32)
+    obs, rew, done = eng.step(bad)
+    oobs, _, _ = ora.step(ok)
+    assert np.array_equal(obs.cpu().numpy(), oobs)
+    eng.close()
+
+
+def test_state_roundtrip_encode_and_exchange(layout_params):
+    """get/set round trip, device export/import, and featurising exported records elsewhere
+    (the receive side of a compact trajectory exchange) all agree with the oracle."""
+    params = layout_params["unident_s"]
+    n = 777
+    acts = _mixed_actions("unident_s", 120, n, seed=9)
+    ora = oracle.OracleVecEnv(params, n, nthreads=4)
+    eng = _engine(params, n)
+    dacts = torch.from_numpy(acts).cuda()
+    for t in range(120):
+        eng.step(dacts[t]); ora.step(acts[t])
+    recs = eng.export_states()
+    other = _engine(params, 10)
+    enc = other.encode_states(recs)                       # 777 records through a 10-kitchen engine
+    assert np.array_equal(enc.cpu().numpy(), ora.encode())
+    tiles, players, ts = eng.get_state()
+    eng2 = _engine(params, n)
+    eng2.set_state(tiles, players, ts)
+    assert np.array_equal(eng2.observe().cpu().numpy(), ora.encode())
+    eng3 = _engine(params, n)
+    eng3.import_states(recs)
+    for e in (eng, eng2, eng3):
+        obs, rew, done = e.step(dacts[0])
+    oobs, orew, _ = ora.step(acts[0])
+    for e in (eng, eng2, eng3):
+        assert np.array_equal(e.obs.cpu().numpy(), oobs) and np.array_equal(e.reward.cpu().numpy(), orew)
+        e.close()
+    other.close()
+
+
+def test_reset_all_and_rollout_time_major(layout_params):
+    params = layout_params["random3"]
+    n, T = 300, 205
+    acts = _mixed_actions("random3", T, n, seed=4)
+    ora = oracle.OracleVecEnv(params, n)
+    eng = _engine(params, n)
+    dacts = torch.from_numpy(acts).cuda()
+    eng.step(dacts[0]); eng.step(dacts[1])
+    start = eng.reset_all().cpu().numpy()
+    assert np.array_equal(start, ora.reset_all())
+    obs = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    eng.rollout(dacts, T, obs=obs, reward=rew, done=done)     # T launches from C, time-major outputs
+    for t in range(T):
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(obs[t].cpu().numpy(), oobs), t
+        assert np.array_equal(rew[t].cpu().numpy(), orew) and np.array_equal(done[t].cpu().numpy(), odone)
+    assert int(done[199].sum()) == n and int(done.sum()) == n
+    eng.close()
+
+
+def test_full_size_properties(layout_params):
+    """65 536 kitchens (BASELINE.json's size): size-independent checks.
+    (1) replication: kitchens fed identical action streams stay identical to kitchen 0;
+    (2) sampled parity: 512 scattered kitchens with their own streams match the oracle stepped on
+        exactly those streams; (3) every kitchen reports done exactly at steps 200, 400."""
+    params = layout_params["simple"]
+    n, T = 65536, 402
+    rng = np.random.default_rng(21)
+    sample = np.sort(rng.choice(np.arange(1, n), size=512, replace=False))
+    own = _mixed_actions("simple", T, 512, seed=8)
+    base = _mixed_actions("simple", T, 1, seed=3)[:, :, 0]
+    eng = _engine(params, n)
+    ora = oracle.OracleVecEnv(params, 512, nthreads=8)
+    ref0 = oracle.OracleVecEnv(params, 1)
+    idx = torch.from_numpy(sample).cuda()
+    mask = torch.ones(n, dtype=torch.bool, device="cuda"); mask[idx] = False
+    for t in range(T):
+        a = torch.from_numpy(np.repeat(base[t][:, None], n, axis=1)).cuda().to(torch.int32)
+        a[:, idx] = torch.from_numpy(own[t]).cuda()
+        obs, rew, done = eng.step(a)
+        oobs, orew, odone = ora.step(own[t])
+        o0, r0, d0 = ref0.step(base[t].reshape(2, 1))
+        assert np.array_equal(obs[:, idx].cpu().numpy(), oobs), t
+        assert np.array_equal(rew[:, idx].cpu().numpy(), orew), t
+        rest = obs[:, mask]
+        assert bool((rest == torch.from_numpy(o0).cuda()).all()), t
+        assert bool((rew[:, mask] == int(r0[0, 0])).all()), t
+        assert int(done.sum()) == (n if t in (199, 399) else 0), t
+    eng.close()
