@@ -171,8 +171,8 @@ class OvercookedEngine:
         native.check(self._L.oc_encode_states(self._handle, _ptr(records), n, _ptr(obs), self._stream()))
         return obs
 
-    def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0):
-        native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush))
+    def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0, waves_per_cu=0):
+        native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush, waves_per_cu))
 
     # ------------------------------------------------------------------ state import/export
     def export_states(self, first=0, count=None, out=None):

@@ -90,7 +90,7 @@ def lib():
     L.oc_num_kitchens.restype = i64
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
     L.oc_device_id.argtypes = [vp]
-    L.oc_set_tuning.argtypes = [vp, i32, i32]
+    L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
     L.oc_last_error.argtypes = []
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_abi_version.argtypes = []

@@ -80,14 +80,14 @@ def test_hip_vs_oracle_batch(layout, layout_params):
     eng.close()
 
 
-@pytest.mark.parametrize("kpw,passes", [(4, 1), (8, 2), (16, 4), (32, 8), (64, 3), (12, 5)])
-def test_tuning_does_not_change_results(kpw, passes, layout_params):
+@pytest.mark.parametrize("kpw,passes,wpc", [(4, 1, 1), (8, 2, 4), (16, 4, 8), (32, 8, 2), (40, 3, 3), (12, 5, 16), (16, 2, 32)])
+def test_tuning_does_not_change_results(kpw, passes, wpc, layout_params):
     params = layout_params["random1"]            # S = 25: odd record padding, non-16B kitchen planes
     n, T = 1003, 230
     acts = _mixed_actions("random1", T, n, seed=5)
     ora = oracle.OracleVecEnv(params, n, nthreads=8)
     eng = _engine(params, n)
-    eng.set_tuning(kpw, passes)
+    eng.set_tuning(kpw, passes, wpc)
     dacts = torch.from_numpy(acts).cuda()
     for t in range(T):
         obs, rew, done = eng.step(dacts[t])

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-wave phase timeline of ONE step launch (diagnostic build path: s_memrealtime stamps, 100 MHz).
+Stamps: 0 wave start, 1 prologue done (tables + first state block landed), 2 first transition done,
+3 first plane flush issued, 4 last plane flush issued, 5 wave end.  Times in us relative to the
+earliest wave start."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from diverse_conventions_amd import OvercookedEngine, get_base_layout_params, native
+
+layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+kpw = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+g = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+w = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+params = get_base_layout_params(layout, 200)
+eng = OvercookedEngine(params, n, 0)
+eng.set_tuning(kpw, g, w)
+actions = torch.randint(0, 6, (8, 2, n), device="cuda", dtype=torch.int32)
+eng.rollout(actions, 20)
+torch.cuda.synchronize()
+L = native.lib()
+L.oc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+native.check(L.oc_debug_trace(eng._handle, 1, None, 0))
+eng.step(actions[0])
+nw = min((n + kpw - 1) // kpw, w * 256)
+buf = np.zeros((nw, 8), dtype=np.uint64)
+native.check(L.oc_debug_trace(eng._handle, 0, buf.ctypes.data_as(ctypes.c_void_p), nw))
+t = buf[:, :6].astype(np.float64) / 100.0          # 100 MHz -> us
+t0 = t[:, 0].min()
+names = ["start", "prologue", "transition", "first flush", "last flush", "end"]
+print(f"{layout} N={n} kpw={kpw} passes={g} waves/CU={w}: {nw} waves")
+for i, nm in enumerate(names):
+    c = t[:, i] - t0
+    print(f"  {nm:12s} min {c.min():6.2f}  p10 {np.percentile(c,10):6.2f}  median {np.median(c):6.2f}  p90 {np.percentile(c,90):6.2f}  max {c.max():6.2f}")
+d = np.diff(t, axis=1)
+for i in range(5):
+    print(f"  {names[i]:>12s} -> {names[i+1]:12s} median {np.median(d[:, i]):6.2f} us   p90 {np.percentile(d[:, i],90):6.2f}")
+xcc = buf[:, 6]
+print("  waves per XCC id:", np.bincount(xcc.astype(np.int64) & 0xF))
+eng.close()
