@@ -171,6 +171,11 @@ class OvercookedEngine:
         native.check(self._L.oc_encode_states(self._handle, _ptr(records), n, _ptr(obs), self._stream()))
         return obs
 
+    @property
+    def kernel_build_info(self):
+        """'specialised for gfx950...' when the per-engine hiprtc build is in use, else why not."""
+        return self._L.oc_kernel_build_info(self._handle).decode()
+
     def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0, waves_per_cu=0):
         native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush, waves_per_cu))
 

@@ -12,6 +12,8 @@ REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip")]
+KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")
+KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: KERNEL_HEADER as a C++ raw string
 INCLUDE = os.path.join(REPO_ROOT, "include")
 
 OC_OK = 0
@@ -23,7 +25,7 @@ SYMBOLS = [
     "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_rollout", "oc_rollout_timed",
     "oc_encode_states", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
-    "oc_last_error", "oc_abi_version",
+    "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
 
 
@@ -47,11 +49,18 @@ class OvercookedNativeError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "overcooked_hip.h")])
+    newest = max(os.path.getmtime(p) for p in SOURCES + [KERNEL_HEADER, os.path.join(INCLUDE, "overcooked_hip.h")])
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
+    # the kernel header is also embedded as text: oc_create() re-compiles it per engine with hiprtc
+    with open(KERNEL_HEADER) as f:
+        text = f.read()
+    assert ')OCKSRC"' not in text
+    with open(KERNEL_SRC_INC, "w") as f:
+        f.write('// generated from oc_step_kernel.h by native.build() -- do not edit\n'
+                'static const char oc_step_kernel_src[] = R"OCKSRC(' + text + ')OCKSRC";\n')
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE,
-           "-o", LIB_PATH] + SOURCES
+           "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -93,6 +102,10 @@ def lib():
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
     L.oc_last_error.argtypes = []
     L.oc_last_error.restype = ctypes.c_char_p
+    L.oc_kernel_build_info.argtypes = [vp]
+    L.oc_kernel_build_info.restype = ctypes.c_char_p
+    L.oc_debug_jit_compile.argtypes = [ctypes.POINTER(OcLayoutParams), i64, ctypes.c_char_p, ctypes.POINTER(i64),
+                                       ctypes.c_char_p, i64]
     L.oc_abi_version.argtypes = []
     for name in SYMBOLS:
         fn = getattr(L, name)
@@ -105,6 +118,16 @@ def lib():
 def check(status):
     if status != OC_OK:
         raise OvercookedNativeError(status, lib().oc_last_error().decode())
+
+
+def jit_compile_check(params, num_kitchens=4096, arch="gfx950"):
+    """Compile the per-engine (hiprtc) build of the step kernel for `params` without a GPU.
+    -> code object size in bytes; raises OvercookedNativeError with the compiler log on failure."""
+    size = ctypes.c_int64(0)
+    log = ctypes.create_string_buffer(8192)
+    check(lib().oc_debug_jit_compile(ctypes.byref(make_params(params)), num_kitchens, arch.encode(), ctypes.byref(size),
+                                     log, len(log)))
+    return size.value
 
 
 def make_params(params):

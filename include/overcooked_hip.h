@@ -134,6 +134,10 @@ int oc_device_id(const oc_engine *e);
  * 0 keeps the current value. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
 
+/* Which kernel build serves this engine: "specialised for gfx950..." when the per-engine hiprtc build
+ * succeeded at oc_create, otherwise the reason the generic ahead-of-time kernel is in use. */
+const char *oc_kernel_build_info(const oc_engine *e);
+
 const char *oc_last_error(void);
 int oc_abi_version(void);
 

@@ -28,18 +28,19 @@ L.oc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, cty
 native.check(L.oc_debug_trace(eng._handle, 1, None, 0))
 eng.step(actions[0])
 nw = min((n + kpw - 1) // kpw, w * 256)
-buf = np.zeros((nw, 8), dtype=np.uint64)
+buf = np.zeros((nw, 16), dtype=np.uint64)
 native.check(L.oc_debug_trace(eng._handle, 0, buf.ctypes.data_as(ctypes.c_void_p), nw))
-t = buf[:, :6].astype(np.float64) / 100.0          # 100 MHz -> us
+order = [0, 1, 6, 7, 8, 2, 3, 4, 5]
+t = buf[:, order].astype(np.float64) / 100.0          # 100 MHz -> us
 t0 = t[:, 0].min()
-names = ["start", "prologue", "transition", "first flush", "last flush", "end"]
+names = ["start", "prologue", "T: lds fill", "T: loads", "T: interacts", "transition", "first flush", "last flush", "end"]
 print(f"{layout} N={n} kpw={kpw} passes={g} waves/CU={w}: {nw} waves")
 for i, nm in enumerate(names):
     c = t[:, i] - t0
     print(f"  {nm:12s} min {c.min():6.2f}  p10 {np.percentile(c,10):6.2f}  median {np.median(c):6.2f}  p90 {np.percentile(c,90):6.2f}  max {c.max():6.2f}")
 d = np.diff(t, axis=1)
-for i in range(5):
+for i in range(len(names) - 1):
     print(f"  {names[i]:>12s} -> {names[i+1]:12s} median {np.median(d[:, i]):6.2f} us   p90 {np.percentile(d[:, i],90):6.2f}")
-xcc = buf[:, 6]
+xcc = buf[:, 10]
 print("  waves per XCC id:", np.bincount(xcc.astype(np.int64) & 0xF))
 eng.close()
