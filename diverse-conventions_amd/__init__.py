@@ -9,9 +9,10 @@ from .vectorobservation import VectorObservation
 from .engine import OvercookedEngine
 from .overcooked_env import OvercookedMadrona
 from .env_utils import generate_env
+from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments, pairing_segments
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "OvercookedMadrona",
-    "generate_env",
+    "generate_env", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
 ]

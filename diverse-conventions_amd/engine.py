@@ -176,6 +176,18 @@ class OvercookedEngine:
         """'specialised for gfx950...' when the per-engine hiprtc build is in use, else why not."""
         return self._L.oc_kernel_build_info(self._handle).decode()
 
+    def encode_states_into(self, records, obs_global, kitchen_offset):
+        """Featurise `records` (n native state records) into kitchens [kitchen_offset, kitchen_offset+n) of a
+        larger int8 [P, N_total, W, H, C] tensor (one launch, no staging copy)."""
+        n = records.numel() * records.element_size() // self.record_bytes
+        per_kitchen = self.size * CHANNELS
+        if obs_global.dim() != 5 or not obs_global.is_contiguous() or kitchen_offset + n > obs_global.shape[1]:
+            raise ValueError("obs_global must be a contiguous [P, N_total, W, H, C] tensor that holds the block")
+        dst = obs_global.data_ptr() + kitchen_offset * per_kitchen
+        native.check(self._L.oc_encode_states_strided(self._handle, _ptr(records), n, ctypes.c_void_p(dst),
+                                                      obs_global.shape[1] * per_kitchen, self._stream()))
+        return obs_global
+
     def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0, waves_per_cu=0):
         native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush, waves_per_cu))
 

@@ -1,0 +1,107 @@
+"""Kitchens across the GPUs of one node: sharding, convention-pairing segments, trajectory exchange.
+
+The reference runs everything on one GPU (`gpu_id=0`, train/env_utils.py:26) and has no collective
+code; this module is the new multi-GPU capability of the north star.  Kitchens never interact, so a
+rollout needs NO communication: every rank owns a contiguous block of kitchens and keeps the full
+pairing-segment structure at 1/world size.  The only exchange is once per PPO update, when the
+cross-play / mixed-play loss wants the whole batch: ranks all-gather *compact* trajectories
+(native state records + actions + rewards + dones: 4S+16 B per kitchen-step instead of 40S B of
+observations) over RCCL/xGMI and re-featurise peers' shards locally with the encode kernel.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class KitchenShard:
+    """Contiguous block [first, first+count) of `total` kitchens owned by `rank` of `world`."""
+    total: int
+    world: int
+    rank: int
+
+    @property
+    def count(self) -> int:
+        return self.total // self.world + (1 if self.rank < self.total % self.world else 0)
+
+    @property
+    def first(self) -> int:
+        base, extra = divmod(self.total, self.world)
+        return self.rank * base + min(self.rank, extra)
+
+    def counts(self) -> List[int]:
+        return [KitchenShard(self.total, self.world, r).count for r in range(self.world)]
+
+
+@dataclass(frozen=True)
+class Segment:
+    """Kitchens [start, stop) of one env object played by (ego policy, partner policy).
+    policy index 0 = the convention being trained, i >= 1 = frozen convention i-1."""
+    name: str
+    start: int
+    stop: int
+    ego_policy: int
+    partner_policy: int
+
+
+def pairing_segments(threads: int, n_conventions: int) -> List[Segment]:
+    """Segment map of the reference's CoMeDi env for the (k+1)-th convention, k = n_conventions
+    already trained: `threads*(2k+1)` kitchens laid out [SP | XP0_0..XP0_{k-1} | XP1_0..XP1_{k-1}]
+    (train/XD/serial.py:27); ego side plays [new]*(k+1) + [conv_i] (xd_player.py:94), partner side
+    [new] + [conv_i] + [new]*k (xd_player.py:76-77)."""
+    k = n_conventions
+    segs = [Segment("SP", 0, threads, 0, 0)]
+    for i in range(k):
+        segs.append(Segment(f"XP0_{i}", threads * (1 + i), threads * (2 + i), 0, 1 + i))
+    for i in range(k):
+        segs.append(Segment(f"XP1_{i}", threads * (1 + k + i), threads * (2 + k + i), 1 + i, 0))
+    return segs
+
+
+def local_segments(threads_total: int, n_conventions: int, world: int, rank: int) -> List[Segment]:
+    """The same segment structure on every GPU at 1/world of the threads: each rank
+    evaluates every convention pair locally with replicated policy weights."""
+    return pairing_segments(KitchenShard(threads_total, world, rank).count, n_conventions)
+
+
+class TrajectoryExchange:
+    """All-gather of compact time-major trajectory shards.
+
+    Every rank contributes tensors whose leading dims are [T, n_local, ...]; the result keeps peers'
+    shards as separate leading-dim blocks, [world, T, n_local, ...], which is exactly what
+    `all_gather_into_tensor` produces -- no permute, no staging copy.  Shards must be equal-sized
+    (use a kitchen count divisible by the world size)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        local = local.contiguous()
+        if self.world == 1:
+            return local.unsqueeze(0)
+        out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        try:
+            dist.all_gather_into_tensor(out, local, group=self.group)
+        except (RuntimeError, NotImplementedError):          # backend without the fused form
+            dist.all_gather(list(out.unbind(0)), local, group=self.group)
+        return out
+
+    def gather_trajectory(self, records, actions, reward, done):
+        """records int32 [T, n, rec/4]; actions [T, P, n]; reward [T, n]; done [T, n]
+        -> dict of [world, ...] tensors (peer r's shard at index r)."""
+        return {"records": self.all_gather(records), "actions": self.all_gather(actions),
+                "reward": self.all_gather(reward), "done": self.all_gather(done)}
+
+    def featurize(self, engine, records_all, t, out=None):
+        """Observation of every kitchen of every rank at time t from the gathered records:
+        int8 [P, world*n, W, H, C], peers' shards in rank order (one encode launch per peer)."""
+        world, _, n = records_all.shape[:3]
+        if out is None:
+            out = torch.empty((2, world * n, engine.width, engine.height, 20), dtype=torch.int8, device=records_all.device)
+        for r in range(world):
+            engine.encode_states_into(records_all[r, t], out, r * n)
+        return out

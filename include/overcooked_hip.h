@@ -115,6 +115,10 @@ int oc_rollout_timed(oc_engine *e, const void *d_actions, int action_dtype, int6
 /* Featurise n externally supplied state records (device pointer, record format above) without
  * touching the engine's own kitchens: the receive side of a compact trajectory exchange. */
 int oc_encode_states(oc_engine *e, const void *d_states, int64_t n, int8_t *d_obs, void *stream);
+/* Same, writing viewer v's [n][W][H][C] block at d_obs + v * obs_player_stride bytes: lets a receiver
+ * drop a peer's shard at its kitchen offset inside a larger [P][N_total][W][H][C] tensor. */
+int oc_encode_states_strided(oc_engine *e, const void *d_states, int64_t n, int8_t *d_obs, int64_t obs_player_stride,
+                             void *stream);
 
 /* State import / export.  get/set are synchronous host copies (tests, checkpoints);
  * export/import are stream-ordered device-to-device copies of `count` records starting at `first`. */

@@ -1,0 +1,87 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header declares, reports
+errors by code instead of crashing, and its per-engine kernel build compiles for gfx950 (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from diverse_conventions_amd import get_base_layout_params, layout_names, native
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "overcooked_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = native.lib()
+    declared = header_functions()
+    assert sorted(native.SYMBOLS) == declared
+    for name in declared:
+        assert getattr(L, name) is not None, name
+    assert L.oc_abi_version() == 1
+
+
+def test_layout_struct_matches_header():
+    # 7 scalars + 2x16 recipe tables + 2x2 start coordinates + 256 terrain codes, all int32
+    assert ctypes.sizeof(native.OcLayoutParams) == 4 * (7 + 32 + 4 + 256)
+
+
+def _create(params, n=8):
+    L = native.lib()
+    h = ctypes.c_void_p()
+    p = native.make_params(params) if isinstance(params, dict) else params
+    rc = L.oc_create(ctypes.byref(p), n, 0, ctypes.byref(h))
+    if rc == 0:
+        L.oc_destroy(h)
+    return rc, L.oc_last_error().decode()
+
+
+def test_error_codes_not_crashes():
+    import torch
+    L = native.lib()
+    good = get_base_layout_params("simple", 200)
+    rc = L.oc_create(None, 8, 0, None)
+    assert rc == -1 and "NULL" in L.oc_last_error().decode()
+    rc, msg = _create(good, n=0)
+    assert rc == -1 and "n_kitchens" in msg
+    bad = dict(good, terrain=[9] + good["terrain"][1:])
+    rc, msg = _create(bad)
+    assert rc == -1 and "terrain[0]" in msg
+    unwalled = dict(good, terrain=[0] + good["terrain"][1:])
+    rc, msg = _create(unwalled)
+    assert rc == -1 and "walled" in msg
+    p = native.make_params(good)
+    p.num_players = 3
+    rc, msg = _create(p)
+    assert rc == -2 and "2-player" in msg
+    slow = dict(good, recipe_times=[200] * 16)
+    rc, msg = _create(slow)
+    assert rc == -2 and "recipe_times" in msg
+    start_in_wall = dict(good, start_player_x=[0, 3])
+    rc, msg = _create(start_in_wall)
+    assert rc == -1 and "start position" in msg
+    if not torch.cuda.is_available():
+        rc, msg = _create(good)
+        assert rc == -4 and "no CPU fallback" in msg            # never a silent CPU path
+    assert L.oc_destroy(None) == 0
+    assert L.oc_step(None, None, 0, None, None, None, None) == -1
+
+
+def test_python_wrapper_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diverse_conventions_amd import OvercookedMadrona
+    with pytest.raises(native.OvercookedNativeError) as e:
+        OvercookedMadrona("simple", 4, 0)
+    assert e.value.status == -4
+
+
+@pytest.mark.parametrize("name", [n for n in layout_names() if get_base_layout_params(n, 200)["num_players"] == 2])
+def test_per_engine_kernel_build_compiles_for_gfx950(name):
+    size = native.jit_compile_check(get_base_layout_params(name, 200), arch="gfx950")
+    assert size > 10_000

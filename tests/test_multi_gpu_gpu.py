@@ -1,0 +1,78 @@
+"""GPU checks of the pieces that sit on either side of the rollout: peers' shards re-featurised from
+compact records (the receive side of the RCCL all-gather), and BASELINE config 3's shape -- the five
+classic layouts x 8192 kitchens with the reference's convention-pairing segments."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_peer_shards_refeaturised_in_place(layout_params):
+    from diverse_conventions_amd import KitchenShard, OvercookedEngine, TrajectoryExchange
+    params = layout_params["random3"]
+    total, world, T = 96, 2, 25
+    rng = np.random.default_rng(2)
+    acts = rng.integers(0, 6, size=(T, 2, total)).astype(np.int32)
+    ref = oracle.OracleVecEnv(params, total)
+    engines = [OvercookedEngine(params, KitchenShard(total, world, r).count, 0) for r in range(world)]
+    recs = [[] for _ in range(world)]
+    want = []
+    for t in range(T):
+        for r, eng in enumerate(engines):
+            sh = KitchenShard(total, world, r)
+            eng.step(torch.from_numpy(acts[t][:, sh.first:sh.first + sh.count].copy()).cuda())
+            recs[r].append(eng.export_states())
+        want.append(ref.step(acts[t])[0].copy())
+    # what all_gather_into_tensor yields on every rank: [world, T, n, rec/4]
+    gathered = torch.stack([torch.stack(r) for r in recs])
+    ex = TrajectoryExchange()
+    assert ex.world == 1 and ex.all_gather(recs[0][0]).shape[0] == 1
+    for t in (0, 7, T - 1):
+        obs = ex.featurize(engines[0], gathered, t)
+        assert obs.shape == (2, total, 8, 5, 20)
+        assert np.array_equal(obs.cpu().numpy(), want[t]), t
+    for e in engines:
+        e.close()
+
+
+def test_config3_five_layouts_with_pairing_segments(layout_params):
+    """5 classic layouts x 8192 kitchens, 8 conventions -> 15 segments of 546 (+2 spare) kitchens.
+    Each (policy, side) pair draws its own action stream, so segments really differ; a sample of
+    kitchens per layout is checked against the oracle, and every engine steps on its own stream."""
+    from diverse_conventions_amd import CLASSIC_LAYOUTS, OvercookedEngine, pairing_segments
+    n, k, T = 8192, 7, 210
+    threads = n // (2 * k + 1)
+    segs = pairing_segments(threads, k)
+    assert len(segs) == 15 and segs[-1].stop <= n
+    rng = np.random.default_rng(9)
+    # one action tape per policy (index 0 = learner, 1..7 frozen conventions) and side
+    tapes = rng.integers(0, 6, size=(k + 1, 2, T, threads)).astype(np.int32)
+    acts = np.full((T, 2, n), 4, dtype=np.int32)
+    for s in segs:
+        acts[:, 0, s.start:s.stop] = tapes[s.ego_policy, 0]
+        acts[:, 1, s.start:s.stop] = tapes[s.partner_policy, 1]
+    sample = np.sort(rng.choice(n, size=256, replace=False))
+    engines, oracles, streams = [], [], []
+    for name in CLASSIC_LAYOUTS:
+        engines.append(OvercookedEngine(layout_params[name], n, 0))
+        oracles.append(oracle.OracleVecEnv(layout_params[name], len(sample), nthreads=4))
+        streams.append(torch.cuda.Stream())
+    dacts = torch.from_numpy(acts).cuda()
+    idx = torch.from_numpy(sample).cuda()
+    torch.cuda.synchronize()
+    for t in range(T):
+        for eng, st in zip(engines, streams):
+            with torch.cuda.stream(st):
+                eng.step(dacts[t])
+        torch.cuda.synchronize()
+        for eng, ora in zip(engines, oracles):
+            oobs, orew, odone = ora.step(acts[t][:, sample])
+            assert np.array_equal(eng.obs[:, idx].cpu().numpy(), oobs), t
+            assert np.array_equal(eng.reward[:, idx].cpu().numpy(), orew) and np.array_equal(eng.done[idx].cpu().numpy(), odone)
+    # SP kitchens of one segment got identical tapes on both sides only through policy 0
+    for eng in engines:
+        assert "specialised" in eng.kernel_build_info or "OC_NO_JIT" in eng.kernel_build_info or "OC_ABLATE" in eng.kernel_build_info
+        eng.close()
