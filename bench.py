@@ -28,36 +28,50 @@ def algorithmic_bytes(S, P=2):
     return P * S * (5 * P + 10) + 2 * (4 * S + 6 * P + 4) + 4 * P + 4 * P + 4
 
 
-def cpu_baseline(params, kitchens, budget_s=12.0):
-    """Oracle (CPU port of the reference algorithm) on the same workload, bounded sample."""
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(params, kitchens, budget_s=10.0):
+    """Oracle (CPU port of the reference algorithm) on the same workload, bounded sample.  The thread
+    count is calibrated first (OpenMP over kitchens; oversubscribed boxes get slower with more threads)."""
     import numpy as np
     from oracle import oracle
-    cores = os.cpu_count() or 1
-    env = oracle.OracleVecEnv(params, kitchens, nthreads=cores)
     rng = np.random.default_rng(0)
     acts = rng.integers(0, 6, size=(8, 2, kitchens)).astype(np.int32)
-    env.step(acts[0])                                    # warm-up (page-in, thread pool)
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        env.step(acts[steps % 8])
-        steps += 1
-        el = time.perf_counter() - t0
-        if (el > budget_s and steps >= 8) or steps >= 2000:
-            break
-    multi = 2 * kitchens * steps / el
-    # single-core figure on a smaller slice of the same workload
-    env1 = oracle.OracleVecEnv(params, 4096, nthreads=1)
-    a1 = acts[:, :, :4096].copy()
-    env1.step(a1[0])
-    t0 = time.perf_counter()
-    s1 = 0
-    while time.perf_counter() - t0 < 3.0:
-        env1.step(a1[s1 % 8]); s1 += 1
-    single = 2 * 4096 * s1 / (time.perf_counter() - t0)
-    return {"value": multi, "unit": "agent-env steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps x {kitchens} kitchens, same layout/actions law, OpenMP over kitchens "
-                      f"({el:.1f} s); 1-core: {single:.0f} steps/s on 4096 kitchens",
+
+    def rate(threads, seconds, min_steps):
+        env = oracle.OracleVecEnv(params, kitchens, nthreads=threads)
+        env.step(acts[0])                                # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            env.step(acts[steps % 8])
+            steps += 1
+            el = time.perf_counter() - t0
+            if (el > seconds and steps >= min_steps) or steps >= 5000:
+                return 2 * kitchens * steps / el, steps, el
+
+    cores = usable_cores()
+    single, _, _ = rate(1, 1.5, 2)
+    candidates = sorted({c for c in (2, 4, 8, 16, 32, 64, cores) if 1 < c <= cores})
+    best_threads, best = 1, single
+    for c in candidates:
+        r, _, _ = rate(c, 0.7, 2)
+        if r > best:
+            best_threads, best = c, r
+    value, steps, el = rate(best_threads, budget_s, 8)
+    return {"value": value, "unit": "agent-env steps/s", "cores": best_threads, "kind": "port",
+            "sample": f"{steps} steps x {kitchens} kitchens ({el:.1f} s), same layout and action law as the GPU run, "
+                      f"C oracle with OpenMP over kitchens, best of {[1] + candidates} threads on a host with {cores} usable cores",
             "value_1core": single,
             "reference_python_survey_container": {"value": 64000, "cores": 1,
                                                   "note": "reference SimplifiedOvercooked.n_step, BASELINE.md section 2 (other host)"}}
@@ -115,6 +129,7 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     wall, kernel_ms = float(stats[0]), float(stats[1])
 
+    build_info = eng.kernel_build_info
     if rank == 0:
         bytes_per_launch = algorithmic_bytes(S) * n
         per_launch_s = kernel_ms / 1e3 / args.steps
@@ -140,7 +155,8 @@ def main():
                        "layout": args.layout, "kitchens_per_gpu": n, "parallelism": f"kitchen-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "oc_step_kernel<STEP,i32,vec16>", "bytes_per_launch": bytes_per_launch,
+                         "kernel": "oc_jit_step_i32_v16" if "specialised" in build_info else "oc_step_kernel<STEP,i32,vec16>",
+                         "kernel_build": build_info, "bytes_per_launch": bytes_per_launch,
                          "us_per_launch": per_launch_s * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:
