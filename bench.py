@@ -57,7 +57,7 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
             env.step(acts[steps % 8])
             steps += 1
             el = time.perf_counter() - t0
-            if (el > seconds and steps >= min_steps) or steps >= 5000:
+            if (el > seconds and steps >= min_steps) or steps >= 200000:
                 return 2 * kitchens * steps / el, steps, el
 
     cores = usable_cores()
