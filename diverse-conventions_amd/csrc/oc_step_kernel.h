@@ -33,6 +33,7 @@ namespace oc_dev {
 #define KP_lstride(a) (4 * OC_RECQ + 1)
 #define KP_kpw(a) (OC_KPW)
 #define KP_gpasses(a) (OC_GP)
+#define KP_kpp(a) (OC_KPP)
 #define KP_n_groups(a) ((a).n_groups)
 #define KP_horizon(a) (OC_HORIZON)
 #define KP_dish_rew(a) (OC_DISH_REW)
@@ -55,6 +56,7 @@ namespace oc_dev {
 #define KP_lstride(a) ((a).lstride)
 #define KP_kpw(a) ((a).kpw)
 #define KP_gpasses(a) ((a).gpasses)
+#define KP_kpp(a) ((a).kpp)
 #define KP_n_groups(a) ((a).n_groups)
 #define KP_horizon(a) ((a).horizon)
 #define KP_dish_rew(a) ((a).dish_rew)
@@ -156,7 +158,8 @@ struct StepArgs {
     int32_t recq;               // uint4 per state record
     int32_t lstride;            // LDS dwords per kitchen = 4*recq + 1 (odd -> conflict free)
     int32_t kpw;                // kitchens per wave
-    int32_t gpasses;            // 64-tile passes staged per flush
+    int32_t gpasses;            // passes staged per flush
+    int32_t kpp;                // > 0: kitchen-aligned passes, kpp whole kitchens (kpp*S <= 64 tiles) per pass; 0: flat 64-tile passes
     int32_t n_groups;           // ceil(n_kitchens / kpw)
     int32_t horizon, placement_rew, dish_rew, soup_rew;
     int32_t n_pots, n_counters;
@@ -174,6 +177,7 @@ struct LdsView {
     int32_t *rvalues, *rtimes;
     uint32_t *state;
     uint32_t *kd;               // per-kitchen derived block, 8 dwords: pos0|pos1<<8|done<<16, oh0, oh1, hf0, hf1
+    uint32_t *dump;             // 16 dwords nobody reads: where idle lanes' stores go (cheaper than branching)
     uint32_t *stage[2];
 };
 
@@ -199,6 +203,8 @@ __device__ __forceinline__ LdsView carve(uint32_t *base, const StepArgs &a) {
     uint32_t *p = base + lds_table_dwords(KP_S(a), KP_n_pots(a), KP_n_counters(a));
     v.kd = p;                                                      // 16-byte aligned rows
     p += KP_kpw(a) * kKd;
+    v.dump = p;
+    p += 16;
     v.state = p;
     p += align4(KP_kpw(a) * KP_lstride(a));
     v.stage[0] = p;
@@ -272,7 +278,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // one global_store_dwordx4: the caller guarantees 16-byte alignment (VEC16 launches only)
 __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
     const u32x4 t = {v.x, v.y, v.z, v.w};
+#if defined(OC_NT_STORES) && OC_NT_STORES
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)));
+#else
     *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)) = t;
+#endif
 }
 __device__ __forceinline__ void store4(int8_t *dst, uint32_t v) { *reinterpret_cast<uint32_t *>(dst) = v; }
 
@@ -355,9 +365,14 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         loff[q] = k * KP_lstride(a) + 4 * (c - k * KP_recq(a));
     }
     // tile walk constants: pass p covers flat tiles p*64 + lane, flat = kitchen*S + output tile
+    // flat mode: 64 tiles per pass, tiles of a kitchen may straddle passes; kitchen-aligned mode (kpp > 0):
+    // kpp whole kitchens per pass, so a lane keeps its tile for the whole launch (its table entry and all
+    // its addresses are loop-invariant) at the price of 64 - kpp*S idle lanes
+    const int tpp = KP_kpp(a) > 0 ? KP_kpp(a) * S : kWave;            // tiles per pass
     const int k_first = lane / S, o_first = lane - k_first * S;
-    const int dk = kWave / S, dq = kWave - dk * S;
+    const int dk = KP_kpp(a) > 0 ? KP_kpp(a) : kWave / S, dq = KP_kpp(a) > 0 ? 0 : kWave - dk * S;
 
+    const uint2 tab_fixed = L.out_tab2[o_first];     // kitchen-aligned mode: this lane's tile never changes
     land_prefetch();
     if (KP_trace(a)) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
@@ -447,23 +462,23 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
 
         // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
         const int ntiles = n_valid * S;
-        const int npass = (ntiles + kWave - 1) / kWave;
+        const int npass = (ntiles + tpp - 1) / tpp;
         int k = k_first, o = o_first;
         const int64_t plane_base = k0 * S * kChannels;   // byte offset of this group's kitchens in a viewer plane
         // One tile of phase E is split in two so that two tiles per lane can be in flight: all LDS
         // reads of both tiles are issued before either tile's arithmetic (the kernel runs at 1-2 waves
         // per SIMD, so instruction-level parallelism inside the wave is what hides LDS latency).
-        struct TileIn { uint2 tab; uint4 kq; uint32_t hf1; uint32_t obj; uint32_t *cell; };
-        uint32_t *const dump = L.kd + 5;                 // spare dword of kitchen 0's derived block
+        struct TileIn { uint2 tab; uint4 kq; uint32_t hf1; uint32_t obj; uint32_t *cell; bool active; };
         auto tile_read = [&](int kk, int oo, bool active) {
             TileIn r;
             kk = min(kk, KP_kpw(a) - 1);                     // idle lanes of a ragged last pass read in-range LDS
-            r.tab = L.out_tab2[oo];
+            r.tab = KP_kpp(a) > 0 ? tab_fixed : L.out_tab2[oo];
             r.kq = *reinterpret_cast<const uint4 *>(L.kd + kk * kKd);       // pp, oh0, oh1, hf0
             r.hf1 = L.kd[kk * kKd + 4];
             uint32_t *cell = L.state + kk * KP_lstride(a) + (r.tab.x & 0xff);
             r.obj = *cell;
-            r.cell = active ? cell : dump;               // idle lanes store to a dump word instead of branching
+            r.cell = active ? cell : L.dump;             // idle lanes store to a dump word instead of branching
+            r.active = active;
             return r;
         };
         auto tile_encode = [&](const TileIn &r, int slot) {
@@ -488,7 +503,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
             const uint32_t d3 = r.tab.y | (inpot ? ((obj << 16) & 0xFF000000u) : 0u);      // ch15 = onions in the pot
             const uint32_t d4 = (inpot ? static_cast<uint32_t>(max(tk, 0)) : 0u) | lying | hands;
             const uint32_t thi = r.tab.x >> 16;          // terrain bits of channels 10,11 (ref:165-171)
-            uint32_t *s0 = L.stage[0] + slot, *s1 = L.stage[1] + slot;
+            uint32_t *s0 = r.active ? L.stage[0] + slot : L.dump, *s1 = r.active ? L.stage[1] + slot : L.dump + 8;
             // bytes: [self here, other here, self orient x4, other orient x4, terrain ...]
             s0[0] = e0 | (e1 << 8) | (A << 16); s0[1] = __builtin_amdgcn_alignbit(B, A, 16); s0[2] = __builtin_amdgcn_alignbit(thi, B, 16); s0[3] = d3; s0[4] = d4;
             s1[0] = e1 | (e0 << 8) | (B << 16); s1[1] = __builtin_amdgcn_alignbit(A, B, 16); s1[2] = __builtin_amdgcn_alignbit(thi, A, 16); s1[3] = d3; s1[4] = d4;
@@ -502,24 +517,24 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
             if (KP_ablate(a) & 4) return;
             int p = p0;
             for (; p + 1 < pend; p += 2) {               // two tiles per lane in flight
-                const int slot = ((p - p0) * kWave + lane) * kTileDwords;
-                const TileIn r0 = tile_read(k, o, p * kWave + lane < ntiles);
+                const int slot = ((p - p0) * tpp + lane) * kTileDwords;
+                const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
                 advance();
-                const TileIn r1 = tile_read(k, o, (p + 1) * kWave + lane < ntiles);
+                const TileIn r1 = tile_read(k, o, lane < tpp && (p + 1) * tpp + lane < ntiles);
                 advance();
                 tile_encode(r0, slot);
-                tile_encode(r1, slot + kWave * kTileDwords);
+                tile_encode(r1, slot + tpp * kTileDwords);
             }
             if (p < pend) {
-                const TileIn r0 = tile_read(k, o, p * kWave + lane < ntiles);
+                const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
                 advance();
-                tile_encode(r0, ((p - p0) * kWave + lane) * kTileDwords);
+                tile_encode(r0, ((p - p0) * tpp + lane) * kTileDwords);
             }
         };
         auto flush_passes = [&](int p0) {
             // ---- flush the staged tiles of both viewers: contiguous bytes in the output planes
-            const int gbytes = (min(ntiles - p0 * kWave, KP_gpasses(a) * kWave)) * kChannels;
-            const int64_t goff = plane_base + static_cast<int64_t>(p0) * kWave * kChannels;
+            const int gbytes = (min(ntiles - p0 * tpp, KP_gpasses(a) * tpp)) * kChannels;
+            const int64_t goff = plane_base + static_cast<int64_t>(p0) * tpp * kChannels;
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 if (KP_ablate(a) & 2) break;
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(kWave) void oc_step_kernel(const StepArgs a) { step
 #ifdef OC_JIT
 // entry points of the per-engine build (looked up by name through hipModuleGetFunction)
 #define OC_JIT_ENTRY(name, STEP, ACT64, VEC16) \
-    extern "C" __global__ __launch_bounds__(64) void name(const oc_dev::StepArgs a) { oc_dev::step_body<STEP, ACT64, VEC16, OC_QN>(a); }
+    extern "C" __global__ __launch_bounds__(64, OC_MIN_WAVES) void name(const oc_dev::StepArgs a) { oc_dev::step_body<STEP, ACT64, VEC16, OC_QN>(a); }
 OC_JIT_ENTRY(oc_jit_step_i32_v16, true, false, true)
 OC_JIT_ENTRY(oc_jit_step_i64_v16, true, true, true)
 OC_JIT_ENTRY(oc_jit_step_i32_v4, true, false, false)
