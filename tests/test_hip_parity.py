@@ -101,7 +101,9 @@ def test_tuning_does_not_change_results(kpw, passes, wpc, layout_params):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 63, 64, 65])
-def test_small_and_ragged_sizes(n, layout_params):
+def test_small_and_ragged_sizes(n, layout_params, monkeypatch):
+    if n % 2:
+        monkeypatch.setenv("OC_ALIGNED_PASSES", "1")      # odd sizes also exercise the kitchen-aligned pass mode
     for layout in ("simple", "random0", "unident_s"):
         params = layout_params[layout]
         acts = _mixed_actions(layout, 210, n, seed=n)
