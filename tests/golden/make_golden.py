@@ -330,6 +330,52 @@ def main():
         rec = rollout(oenv, omdp, layout, np.array(acts, np.int32), init=init)
         save(f"micro_{cname}.npz", layout=np.array(layout), **rec)
 
+    # fuzz: arbitrary (also unreachable) states x one random joint action each.  Objects of any kind on any
+    # tile, soups with any ingredient count / tick (cooking soups on counters, idle full soups, foreign
+    # objects in pots), players anywhere walkable incl. the same tile, any held object, any timestep.
+    for name in ("simple", "unident_s", "mdp_test", "random0"):
+        prm = params[name]
+        S = prm["width"] * prm["height"]
+        air = [i for i, t in enumerate(prm["terrain"]) if t == 0]
+        Wd_ = prm["width"]
+        facing = [(p_, o_) for p_ in air for o_, d_ in enumerate((-Wd_, Wd_, 1, -1))
+                  if prm["terrain"][p_ + d_] in (1, 3, 4, 5, 6) or (prm["terrain"][p_ + d_] == 2 and o_ == 0)]
+        rng = np.random.default_rng(sum(map(ord, name)) + 17)
+        cases = dict(tiles=[], players=[], timestep=[], actions=[], n_tiles=[], n_players=[], n_timestep=[],
+                     reward_per_player=[], done=[], obs=[], init_obs=[])
+
+        def rand_obj():
+            nm = int(rng.integers(1, 5))
+            if nm == 4:
+                return (4, int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.integers(-1, 26)))
+            return (nm, 0, 0, -1)
+        for _ in range(500):
+            tiles = np.zeros((S, 4), np.int8)
+            for pos in rng.choice(S, size=int(rng.integers(0, 7)), replace=False):
+                tiles[pos] = rand_obj()
+            for pos in [i for i, t in enumerate(prm["terrain"]) if t == 1]:
+                if rng.random() < 0.7:      # pots mostly hold soups in every phase of cooking
+                    tiles[pos] = (4, int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.choice([-1, -1, 0, 5, 19, 20, 21])))
+            players = np.zeros((2, 6), np.int8)
+            for i in range(2):
+                held = rand_obj() if rng.random() < 0.6 else (0, 0, 0, 0)
+                if rng.random() < 0.7:      # stand in front of something interactive, facing it
+                    pos_or = facing[int(rng.integers(0, len(facing)))]
+                else:
+                    pos_or = (int(rng.choice(air)), int(rng.integers(0, 4)))
+                players[i] = pos_or + held
+            ts = int(rng.integers(0, 200)) if rng.random() < 0.9 else 199
+            act = rng.integers(0, 6, size=(1, 2)).astype(np.int32)
+            if rng.random() < 0.5:
+                act[0, int(rng.integers(0, 2))] = 5          # bias towards INTERACT
+            rec = rollout(oenv, omdp, name, act, init=(tiles, players, np.int32(ts)))
+            cases["tiles"].append(tiles); cases["players"].append(players); cases["timestep"].append(ts)
+            cases["actions"].append(act[0]); cases["init_obs"].append(rec["init_obs"])
+            cases["n_tiles"].append(rec["tiles"][0]); cases["n_players"].append(rec["players"][0])
+            cases["n_timestep"].append(rec["timestep"][0]); cases["reward_per_player"].append(rec["reward_per_player"][0])
+            cases["done"].append(rec["done"][0]); cases["obs"].append(rec["obs"][0])
+        save(f"fuzz_{name}.npz", **{k: np.array(v) for k, v in cases.items()})
+
     # a12) the batched surface: reference SyncVectorEnv over 3 reference envs, 420 steps (2 resets)
     import torch
     vec = venv.SyncVectorEnv([lambda: oenv.SimplifiedOvercooked("simple") for _ in range(3)], device="cpu")

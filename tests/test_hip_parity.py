@@ -43,6 +43,32 @@ def test_hip_replays_reference_fixture(path, layout_params):
     eng.close()
 
 
+FUZZ = golden_files("fuzz_")
+
+
+@pytest.mark.parametrize("path", FUZZ, ids=[os.path.basename(p)[:-4] for p in FUZZ])
+def test_hip_matches_reference_on_arbitrary_states(path, layout_params):
+    """500 arbitrary (also unreachable) states recorded from the reference, loaded as 500 kitchens:
+    cooking soups on counters, idle full soups, foreign objects in pots, both players on one tile ..."""
+    z = load_golden(path)
+    params = layout_params[os.path.basename(path)[5:-4]]
+    n = len(z["tiles"])
+    for kpw in (0, 4):
+        eng = _engine(params, n)
+        if kpw:
+            eng.set_tuning(kpw, 1, 3)
+        eng.set_state(z["tiles"], z["players"], z["timestep"])
+        assert np.array_equal(eng.observe().cpu().numpy(), np.moveaxis(z["init_obs"], 0, 1))
+        obs, rew, done = eng.step(torch.from_numpy(np.ascontiguousarray(z["actions"].T)).cuda())
+        tiles, players, ts = eng.get_state()
+        assert np.array_equal(done.cpu().numpy().astype(np.uint8), z["done"])
+        assert np.array_equal(rew.cpu().numpy()[0], z["reward_per_player"].sum(axis=1))
+        assert np.array_equal(tiles, z["n_tiles"]) and np.array_equal(players, z["n_players"])
+        assert np.array_equal(ts, z["n_timestep"])
+        assert np.array_equal(obs.cpu().numpy(), np.moveaxis(z["obs"], 0, 1))
+        eng.close()
+
+
 def _mixed_actions(layout, T, n, seed, p_guided=0.85):
     """Per-kitchen action streams: the fixture's guided stream (which cooks and delivers) with
     per-kitchen random substitutions, so kitchens diverge but keep doing useful work."""

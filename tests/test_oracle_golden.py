@@ -87,3 +87,27 @@ def test_oracle_threads_agree(layout_params):
         oa, ra, da = a.step(act)
         ob, rb, db = b.step(act)
         assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+
+
+FUZZ = golden_files("fuzz_")
+
+
+@pytest.mark.parametrize("path", FUZZ, ids=[os.path.basename(p)[:-4] for p in FUZZ])
+def test_oracle_matches_reference_on_arbitrary_states(path, layout_params):
+    """500 arbitrary (also unreachable) states per layout, one joint action each, all as one batch."""
+    z = load_golden(path)
+    params = layout_params[os.path.basename(path)[5:-4]]
+    n = len(z["tiles"])
+    env = oracle.OracleVecEnv(params, n, nthreads=2)
+    env.set_state(z["tiles"], z["players"], z["timestep"])
+    assert np.array_equal(env.encode(), np.moveaxis(z["init_obs"], 0, 1))
+    for i in range(n):
+        _, _, _, r = oracle.transition(params, z["tiles"][i], z["players"][i], int(z["timestep"][i]), z["actions"][i])
+        assert np.array_equal(r, z["reward_per_player"][i]), i
+    obs, rew, done = env.step(z["actions"].T)
+    tiles, players, ts = env.get_state()
+    assert np.array_equal(done.astype(np.uint8), z["done"])
+    assert np.array_equal(rew[0], z["reward_per_player"].sum(axis=1))
+    assert np.array_equal(tiles, z["n_tiles"]) and np.array_equal(players, z["n_players"]) and np.array_equal(ts, z["n_timestep"])
+    assert np.array_equal(obs, np.moveaxis(z["obs"], 0, 1))
+    assert z["done"].sum() > 0 and (z["reward_per_player"] != 0).sum() > 10      # the fuzz really hits rewards and resets
