@@ -558,6 +558,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         flush_passes(0);
         wave_sync();
         if (KP_trace(a) && stamp[3] == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
+#if defined(OC_NOUNROLL) && OC_NOUNROLL
+#pragma unroll 1
+#endif
         for (int p0 = KP_gpasses(a); p0 < npass; p0 += KP_gpasses(a)) {
             encode_passes(p0);
             wave_sync();

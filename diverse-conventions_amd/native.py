@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
-SOURCES = [os.path.join(CSRC, "overcooked_engine.hip")]
+SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip")]
 KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")
 KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: KERNEL_HEADER as a C++ raw string
 INCLUDE = os.path.join(REPO_ROOT, "include")
@@ -25,7 +25,7 @@ SYMBOLS = [
     "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_rollout", "oc_rollout_timed",
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
-    "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
+    "oc_gae_returns", "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
 
 
@@ -59,7 +59,9 @@ def build(force=False, verbose=False):
     with open(KERNEL_SRC_INC, "w") as f:
         f.write('// generated from oc_step_kernel.h by native.build() -- do not edit\n'
                 'static const char oc_step_kernel_src[] = R"OCKSRC(' + text + ')OCKSRC";\n')
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE,
+    # -ffp-contract=off: rollout_ops.hip must round like the reference's separate torch ops (no FMA); the
+    # engine itself has no floating point
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", INCLUDE,
            "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
     if verbose:
         print(" ".join(cmd))
@@ -101,6 +103,8 @@ def lib():
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
     L.oc_device_id.argtypes = [vp]
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
+    fp = ctypes.c_float
+    L.oc_gae_returns.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, i32, fp, fp, i32, vp]
     L.oc_last_error.argtypes = []
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_kernel_build_info.argtypes = [vp]

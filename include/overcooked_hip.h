@@ -128,6 +128,18 @@ int oc_set_state(oc_engine *e, int64_t first, int64_t count, const void *host_sr
 int oc_export_states(oc_engine *e, int64_t first, int64_t count, void *d_dst, void *stream);
 int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_src, void *stream);
 
+/* ---- runner-side op ----------------------------------------------------------------
+ * Generalised advantage estimation over a whole trajectory batch in one launch; replaces the GAE branches
+ * of SharedReplayBuffer.compute_returns (train/MAPPO/utils/shared_buffer.py:248-304) and the advantage
+ * subtraction of train/MAPPO/r_mappo.py:174-177.  All tensors f32, time-major, M = envs * agents:
+ *   rewards [T][M], value_preds [T+1][M] (row T = next_value), masks [T+1][M], bad_masks [T+1][M] (only read
+ *   with proper_time_limits), returns [T+1][M] (rows 0..T-1 written), advantages [T][M] or NULL.
+ * denormalize != 0: value_preds are ValueNorm/PopArt-normalised, v*vn_std + vn_mean is applied as in
+ * valuenorm.py:74-83.  Bit-identical to the reference's torch expressions (same f32 op order, no FMA). */
+int oc_gae_returns(const float *d_rewards, const float *d_value_preds, const float *d_masks, const float *d_bad_masks,
+                   float *d_returns, float *d_advantages, int64_t T, int64_t M, double gamma, double gae_lambda,
+                   int denormalize, float vn_mean, float vn_std, int proper_time_limits, void *stream);
+
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);
 int oc_obs_shape(const oc_engine *e, int64_t shape5[5]);   /* P, N, W, H, C */
