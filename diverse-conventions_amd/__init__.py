@@ -9,10 +9,12 @@ from .vectorobservation import VectorObservation
 from .engine import OvercookedEngine
 from .overcooked_env import OvercookedMadrona
 from .env_utils import generate_env
+from .trajectory import TrajectoryBuffer
+from .rollout_ops import gae_returns
 from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments, pairing_segments
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "OvercookedMadrona",
-    "generate_env", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
+    "generate_env", "TrajectoryBuffer", "gae_returns", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
 ]

@@ -76,3 +76,39 @@ def test_config3_five_layouts_with_pairing_segments(layout_params):
     for eng in engines:
         assert "specialised" in eng.kernel_build_info or "OC_NO_JIT" in eng.kernel_build_info or "OC_ABLATE" in eng.kernel_build_info
         eng.close()
+
+
+def test_trajectory_buffer_is_filled_in_place(layout_params):
+    """f1: the kernel's destination is the trajectory slot itself (obs int8 [T+1,P,N,W,H,C]) -- stepwise with
+    recorded states, and as one C-side rollout; both equal the oracle, and the records re-encode to the obs."""
+    from diverse_conventions_amd import OvercookedEngine, TrajectoryBuffer
+    params = layout_params["simple"]
+    n, T = 333, 205
+    rng = np.random.default_rng(12)
+    acts = rng.integers(0, 6, size=(T, 2, n)).astype(np.int32)
+    ora = oracle.OracleVecEnv(params, n)
+    want = [ora.encode().copy()]
+    rews, dones = [], []
+    for t in range(T):
+        o, r, d = ora.step(acts[t])
+        want.append(o.copy()); rews.append(r.copy()); dones.append(d.copy())
+    eng = OvercookedEngine(params, n, 0)
+    buf = TrajectoryBuffer(eng, T, store_states=True)
+    dacts = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        o, r, d = buf.step(dacts[t].to(torch.int64).unsqueeze(-1))
+        assert o.data_ptr() == buf.obs[t + 1].data_ptr()          # a view of the slot, not a copy
+    assert np.array_equal(buf.obs.cpu().numpy(), np.stack(want))
+    assert np.array_equal(buf.reward.cpu().numpy(), np.stack(rews)) and np.array_equal(buf.done.cpu().numpy(), np.stack(dones))
+    assert np.array_equal(buf.actions.cpu().numpy(), acts)
+    for t in (0, 77, T):
+        assert np.array_equal(eng.encode_states(buf.records[t]).cpu().numpy(), want[t])
+    with pytest.raises(IndexError):
+        buf.step(dacts[0])
+    buf.after_update()
+    assert np.array_equal(buf.obs[0].cpu().numpy(), want[T]) and buf.t == 0
+    eng2 = OvercookedEngine(params, n, 0)
+    buf2 = TrajectoryBuffer(eng2, T).rollout(dacts)
+    assert np.array_equal(buf2.obs.cpu().numpy(), np.stack(want)) and np.array_equal(buf2.reward.cpu().numpy(), np.stack(rews))
+    assert buf2.agent_view(1).shape == (T + 1, n, 5, 4, 20)
+    eng.close(); eng2.close()
