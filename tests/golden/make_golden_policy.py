@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Golden vectors for segment-batched policy inference: the reference's R_Actor
+(train/MAPPO/r_actor_critic.py:11-76 with CNNBase utils/cnn.py:12-60 and ACTLayer utils/act.py) imported in
+place, three seeded random actors (hidden 64, as train/train_xp.sh uses), real int8 observations of `simple`.
+Stores weights, inputs, action logits, deterministic actions and their log-probs.  Build container only."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, "/root/reference/train")
+from MAPPO.r_actor_critic import R_Actor      # noqa: E402
+
+
+class Space:
+    def __init__(self, shape=None, n=None):
+        self.shape, self.n = shape, n
+
+
+class Discrete(Space):
+    pass
+
+
+if __name__ == "__main__":
+    args = types.SimpleNamespace(hidden_size=64, gain=0.01, use_orthogonal=True, use_policy_active_masks=True,
+                                 use_naive_recurrent_policy=False, use_recurrent_policy=False, recurrent_N=1,
+                                 use_ReLU=True, use_feature_normalization=True, stacked_frames=1, layer_N=2)
+    obs = np.load(os.path.join(HERE, "guided_simple.npz"))["obs"]          # [T, P, W, H, C] int8
+    obs = obs[::3].reshape(-1, 5, 4, 20)[:240]
+    out = {"obs": obs}
+    for k in range(3):
+        torch.manual_seed(100 + k)
+        actor = R_Actor(args, Space((5, 4, 20)), Discrete(n=6))
+        with torch.no_grad():
+            for p in actor.parameters():                  # default init has zero biases and tiny action gains
+                p.add_(torch.randn_like(p) * 0.05)
+            feats = actor.base(torch.from_numpy(obs).float())
+            logits = actor.act.action_out(feats).logits   # normalised log-probabilities
+            act, logp, _ = actor(torch.from_numpy(obs).float(), torch.zeros(len(obs), 1, 64), torch.ones(len(obs), 1),
+                                 deterministic=True)
+        for name, t in actor.state_dict().items():
+            out[f"a{k}.{name}"] = t.numpy()
+        out[f"a{k}.logits"] = logits.numpy()
+        out[f"a{k}.det_action"] = act.numpy()
+        out[f"a{k}.det_logp"] = logp.numpy()
+    np.savez_compressed(os.path.join(HERE, "policy_cases.npz"), **out)
+    print("wrote policy_cases.npz", os.path.getsize(os.path.join(HERE, "policy_cases.npz")) // 1024, "KiB",
+          [k for k in out if k.startswith("a0.")])

@@ -112,3 +112,43 @@ def test_trajectory_buffer_is_filled_in_place(layout_params):
     assert np.array_equal(buf2.obs.cpu().numpy(), np.stack(want)) and np.array_equal(buf2.reward.cpu().numpy(), np.stack(rews))
     assert buf2.agent_view(1).shape == (T + 1, n, 5, 4, 20)
     eng.close(); eng2.close()
+
+
+def test_paired_rollout_eager_and_graph(layout_params):
+    """f2: batched policies for both sides + env step; deterministic actors so that eager, HIP-graph replay and
+    an oracle driven by the same (separately evaluated) actions agree exactly."""
+    import os
+    from conftest import GOLDEN
+    from diverse_conventions_amd import OvercookedEngine
+    from diverse_conventions_amd.policy import StackedActors
+    from diverse_conventions_amd.rollout import PairedRollout
+    z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
+    sds = [{k[len(f"a{i}."):]: z[k] for k in z.files if k.startswith(f"a{i}.") and "logits" not in k and "det_" not in k}
+           for i in range(3)]
+    params = layout_params["simple"]
+    threads, k, T = 64, 2, 40
+    n = threads * (2 * k + 1)
+    actors = StackedActors(sds, (5, 4, 20), "cuda")
+    runs = []
+    for use_graph in (False, True):
+        eng = OvercookedEngine(params, n, 0)
+        ro = PairedRollout(eng, actors, threads, k, deterministic=True)
+        if use_graph:
+            ro.capture()
+            eng.reset_all()                      # capture warm-up stepped the kitchens
+        ora = oracle.OracleVecEnv(params, n)
+        for t in range(T):
+            prev = eng.obs.clone()
+            obs, rew, done = ro.step()
+            acts = ro.actions.cpu().numpy()
+            # the same actions from per-segment, per-policy evaluation (what the reference does sequentially)
+            for p in range(2):
+                for g, seg in enumerate(ro.segments):
+                    pol = seg.ego_policy if p == 0 else seg.partner_policy
+                    a, _ = actors.act(prev[p, seg.start:seg.stop].unsqueeze(0), torch.tensor([pol]), deterministic=True)
+                    assert np.array_equal(a.view(-1).cpu().numpy(), acts[p, seg.start:seg.stop]), (t, p, g)
+            oobs, orew, odone = ora.step(acts)
+            assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew), t
+        runs.append(eng.obs.cpu().numpy().copy())
+        eng.close()
+    assert np.array_equal(runs[0], runs[1])

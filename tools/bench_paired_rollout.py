@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Whole rollout step = batched policies (both sides, all pairing segments) + fused env step, eager vs one HIP
+graph replay per step.  Random-weight actors of the reference architecture (hidden 64)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+from diverse_conventions_amd.policy import StackedActors
+from diverse_conventions_amd.rollout import PairedRollout
+
+
+def random_actor(W, H, hidden=64, gen=None):
+    P = (W - 2) * (H - 2)
+    r = lambda *s: torch.randn(*s, generator=gen) * 0.1
+    return {"base.cnn.cnn.0.weight": r(hidden // 2, 20, 3, 3), "base.cnn.cnn.0.bias": r(hidden // 2),
+            "base.cnn.cnn.3.weight": r(hidden, hidden // 2 * P), "base.cnn.cnn.3.bias": r(hidden),
+            "base.cnn.cnn.5.weight": r(hidden, hidden), "base.cnn.cnn.5.bias": r(hidden),
+            "act.action_out.linear.weight": r(6, hidden), "act.action_out.linear.bias": r(6)}
+
+
+def run(layout, threads, k, steps=200, dtype=torch.float32):
+    params = get_base_layout_params(layout, 200)
+    n = threads * (2 * k + 1)
+    gen = torch.Generator().manual_seed(0)
+    actors = StackedActors([random_actor(params["width"], params["height"], gen=gen) for _ in range(k + 1)],
+                           (params["width"], params["height"], 20), "cuda", dtype=dtype)
+    out = {"layout": layout, "kitchens": n, "segments": 2 * k + 1, "conventions": k + 1, "policy_dtype": str(dtype)}
+    for mode in ("eager", "graph"):
+        eng = OvercookedEngine(params, n, 0)
+        ro = PairedRollout(eng, actors, threads, k)
+        if mode == "graph":
+            ro.capture()
+        for _ in range(10):
+            ro.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ro.step()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / steps * 1e6
+        out[f"{mode}_us_per_step"] = round(us, 1)
+        out[f"{mode}_agent_env_steps_per_s"] = round(2 * n / us * 1e6)
+        eng.close()
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run("cramped_room", 546, 7)), flush=True)          # config-3-sized: 8190 kitchens
+    print(json.dumps(run("cramped_room", 4096, 7)), flush=True)         # 61 440 kitchens
+    print(json.dumps(run("cramped_room", 4096, 7, dtype=torch.bfloat16)), flush=True)
