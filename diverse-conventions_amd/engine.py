@@ -132,6 +132,28 @@ class OvercookedEngine:
         native.check(self._L.oc_reset_all(self._handle, _ptr(obs), self._stream()))
         return obs
 
+    def episode_control(self, reset_mask=None, timesteps=None):
+        """Device-side per-kitchen control: kitchens with reset_mask != 0 go back to the start state, then
+        timestep[k] := timesteps[k] (int32 [N] tensors on the engine's device, either may be None)."""
+        def prep(t):
+            if t is None:
+                return None
+            t = t.to(device=self.device, dtype=torch.int32).contiguous()
+            if t.numel() != self.num_kitchens:
+                raise ValueError("per-kitchen control vectors must have one entry per kitchen")
+            return t
+        m, ts = prep(reset_mask), prep(timesteps)
+        native.check(self._L.oc_episode_control(self._handle, _ptr(m) if m is not None else None,
+                                                _ptr(ts) if ts is not None else None, self._stream()))
+
+    def stagger(self, period=None):
+        """Spread episode phases evenly: kitchen k starts at timestep k*period//N, so resets arrive every few
+        steps instead of all at once (the diagonal schedule of the reference's mixed-play env, generalised)."""
+        period = self.params["horizon"] if period is None else period
+        ts = (torch.arange(self.num_kitchens, device=self.device, dtype=torch.int64) * period // self.num_kitchens)
+        self.episode_control(timesteps=ts.to(torch.int32))
+        return ts
+
     def rollout(self, actions, steps, obs=None, reward=None, done=None):
         """`steps` consecutive launches enqueued from C.  actions [T_act, P, N] are cycled.
         obs/reward/done may carry a leading time axis of length `steps` (time-major trajectory

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", 
 
 # every symbol include/overcooked_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_rollout", "oc_rollout_timed",
+    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed",
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_gae_returns", "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
@@ -88,6 +88,7 @@ def lib():
     L.oc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.oc_observe.argtypes = [vp, vp, vp]
     L.oc_reset_all.argtypes = [vp, vp, vp]
+    L.oc_episode_control.argtypes = [vp, vp, vp, vp]
     L.oc_rollout.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, i64, vp]
     L.oc_rollout_timed.argtypes = [vp, vp, i32, i64, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.oc_encode_states.argtypes = [vp, vp, i64, vp, vp]

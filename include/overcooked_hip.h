@@ -99,6 +99,12 @@ int oc_observe(oc_engine *e, int8_t *d_obs, void *stream);
  * sim.cpp:690-704 resetWorld) and, if d_obs != NULL, write the start observation. */
 int oc_reset_all(oc_engine *e, int8_t *d_obs, void *stream);
 
+/* Per-kitchen episode control on the device (staggered / mixed-play style schedules; the
+ * reference can only reset by reaching the horizon).  d_reset_mask int32[N] or NULL: non-zero entries put that
+ * kitchen back in the start state.  d_timesteps int32[N] or NULL: timestep[k] := d_timesteps[k] (clamped to
+ * 0..horizon-1), so kitchens reach their horizon -- and auto-reset -- at different steps.  Applied mask first. */
+int oc_episode_control(oc_engine *e, const int32_t *d_reset_mask, const int32_t *d_timesteps, void *stream);
+
 /* T consecutive steps enqueued from C (no host work between launches): actions [T_act][P][N] are
  * consumed cyclically (step t uses slice t % T_act); obs/reward/done are overwritten every step
  * unless the *_step_stride (in elements, may be 0) says to advance per step.  Rollout driver for

@@ -258,3 +258,38 @@ def test_full_size_properties(layout_params):
         assert bool((rew[:, mask] == int(r0[0, 0])).all()), t
         assert int(done.sum()) == (n if t in (199, 399) else 0), t
     eng.close()
+
+
+def test_episode_control_masked_reset_and_stagger(layout_params):
+    """f4 plumbing: device-side masked reset and per-kitchen timesteps (staggered horizons) vs the oracle."""
+    params = layout_params["random1"]
+    n, T = 997, 260
+    acts = _mixed_actions("random1", T, n, seed=31)
+    ora = oracle.OracleVecEnv(params, n, nthreads=4)
+    eng = _engine(params, n)
+    dacts = torch.from_numpy(acts).cuda()
+    ts0 = eng.stagger().cpu().numpy().astype(np.int32)          # kitchen k starts at phase k*200//n
+    ora.timestep[:] = ts0
+    assert ts0.min() == 0 and ts0.max() == 199
+    rng = np.random.default_rng(1)
+    dones_per_step = []
+    for t in range(T):
+        if t in (40, 41, 150):
+            mask = (rng.random(n) < 0.3).astype(np.int32)
+            eng.episode_control(reset_mask=torch.from_numpy(mask))
+            tiles, players, ts = ora.get_state()
+            fresh = oracle.OracleVecEnv(params, n)
+            ft, fp, fts = fresh.get_state()
+            sel = mask.astype(bool)
+            tiles[sel], players[sel], ts[sel] = ft[sel], fp[sel], fts[sel]
+            ora.set_state(tiles, players, ts)
+            assert np.array_equal(eng.observe().cpu().numpy(), ora.encode())
+        obs, rew, done = eng.step(dacts[t])
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone), t
+        dones_per_step.append(int(odone.sum()))
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    assert max(dones_per_step[:39]) <= 6 and sum(dones_per_step) > n // 2   # resets arrive a few at a time, every step
+    eng.close()
