@@ -98,9 +98,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # test hooks (a 1-GPU box cannot host two NCCL ranks): OC_BENCH_DEVICE pins every rank to one device,
+    # OC_BENCH_BACKEND=gloo swaps the control-plane backend; the driver's multi-GPU runs use neither
+    if "OC_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["OC_BENCH_DEVICE"])
+    backend = os.environ.get("OC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     params = get_base_layout_params(args.layout, 200)
     S = params["width"] * params["height"]
@@ -124,7 +132,7 @@ def main():
     kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
     barrier()
     wall = time.perf_counter() - t0
-    stats = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     wall, kernel_ms = float(stats[0]), float(stats[1])
