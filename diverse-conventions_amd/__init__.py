@@ -3,9 +3,7 @@
     from diverse_conventions_amd import OvercookedMadrona, generate_env
 """
 from .layouts import ALIASES, CLASSIC_LAYOUTS, get_base_layout_params, layout_names
-from .vectoragent import RandomVectorAgent, VectorAgent
-from .vectorenv import PlayerException, VectorMultiAgentEnv
-from .vectorobservation import VectorObservation
+from .vector_api import PlayerException, RandomVectorAgent, VectorAgent, VectorMultiAgentEnv, VectorObservation
 from .engine import OvercookedEngine
 from .overcooked_env import OvercookedMadrona
 from .env_utils import generate_env

@@ -10,8 +10,7 @@ import torch
 
 from .engine import CHANNELS, NUM_ACTIONS, OvercookedEngine
 from .layouts import get_base_layout_params
-from .vectorenv import VectorMultiAgentEnv
-from .vectorobservation import VectorObservation
+from .vector_api import VectorMultiAgentEnv, VectorObservation
 
 try:                                    # gym is optional: callers only read .shape / .n / class name
     from gym.spaces import Discrete, MultiBinary
