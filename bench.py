@@ -69,10 +69,24 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
         if r > best:
             best_threads, best = c, r
     value, steps, el = rate(best_threads, budget_s, 8)
+    # counterpart of BASELINE config 1: one kitchen, pure-Python restatement of the reference's step + encode
+    from oracle.py_oracle import PyKitchen
+    kitchen = PyKitchen(params)
+    tape = rng.integers(0, 6, size=(4096, 2)).tolist()
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        for a in tape[:512]:
+            kitchen.n_step(a)
+        n1 += 512
+    python_1env = 2 * n1 / (time.perf_counter() - t0)
     return {"value": value, "unit": "agent-env steps/s", "cores": best_threads, "kind": "port",
             "sample": f"{steps} steps x {kitchens} kitchens ({el:.1f} s), same layout and action law as the GPU run, "
                       f"C oracle with OpenMP over kitchens, best of {[1] + candidates} threads on a host with {cores} usable cores",
             "value_1core": single,
+            "python_1env": {"value": python_1env, "cores": 1,
+                            "note": "config 1 counterpart: pure-Python restatement (oracle/py_oracle.py) of the reference's "
+                                    "SimplifiedOvercooked.n_step, 1 kitchen, same host"},
             "reference_python_survey_container": {"value": 64000, "cores": 1,
                                                   "note": "reference SimplifiedOvercooked.n_step, BASELINE.md section 2 (other host)"}}
 

@@ -111,3 +111,43 @@ def test_oracle_matches_reference_on_arbitrary_states(path, layout_params):
     assert np.array_equal(tiles, z["n_tiles"]) and np.array_equal(players, z["n_players"]) and np.array_equal(ts, z["n_timestep"])
     assert np.array_equal(obs, np.moveaxis(z["obs"], 0, 1))
     assert z["done"].sum() > 0 and (z["reward_per_player"] != 0).sum() > 10      # the fuzz really hits rewards and resets
+
+
+# ---- second, independent oracle: pure Python, one kitchen (counterpart of BASELINE config 1) -------------
+from oracle.py_oracle import PyKitchen      # noqa: E402
+
+
+@pytest.mark.parametrize("path", ALL, ids=[os.path.basename(p)[:-4] for p in ALL])
+def test_python_oracle_replays_fixture(path, layout_params):
+    rec = load_golden(path)
+    env = PyKitchen(layout_params[golden_layout_of(path, rec)])
+    env.load(rec["init_tiles"], rec["init_players"], rec["init_timestep"])
+    assert np.array_equal(np.array(env.encode(), np.int8), rec["init_obs"])
+    for t, a in enumerate(rec["actions"]):
+        before = env.dump()
+        probe = PyKitchen(env.p)
+        probe.load(*before)
+        assert probe.transition([int(x) for x in a]) == list(rec["reward_per_player"][t]), t
+        obs, rew, done = env.n_step([int(x) for x in a])
+        tiles, players, ts = env.dump()
+        assert rew == int(rec["reward"][t]) and done == bool(rec["done"][t]), t
+        assert np.array_equal(np.array(tiles, np.int8), rec["tiles"][t]), t
+        assert np.array_equal(np.array(players, np.int16).astype(np.int8), rec["players"][t]) and ts == int(rec["timestep"][t]), t
+        assert np.array_equal(np.array(obs, np.int8), rec["obs"][t]), t
+
+
+@pytest.mark.parametrize("path", FUZZ, ids=[os.path.basename(p)[:-4] for p in FUZZ])
+def test_python_oracle_on_arbitrary_states(path, layout_params):
+    z = load_golden(path)
+    env = PyKitchen(layout_params[os.path.basename(path)[5:-4]])
+    for i in range(len(z["tiles"])):
+        env.load(z["tiles"][i], z["players"][i], z["timestep"][i])
+        assert np.array_equal(np.array(env.encode(), np.int8), z["init_obs"][i]), i
+        probe = PyKitchen(env.p)
+        probe.load(z["tiles"][i], z["players"][i], z["timestep"][i])
+        assert probe.transition([int(x) for x in z["actions"][i]]) == list(z["reward_per_player"][i]), i
+        obs, rew, done = env.n_step([int(x) for x in z["actions"][i]])
+        tiles, players, ts = env.dump()
+        assert done == bool(z["done"][i]) and np.array_equal(np.array(tiles, np.int8), z["n_tiles"][i]), i
+        assert np.array_equal(np.array(players, np.int16).astype(np.int8), z["n_players"][i]) and ts == int(z["n_timestep"][i]), i
+        assert np.array_equal(np.array(obs, np.int8), z["obs"][i]), i
