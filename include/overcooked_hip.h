@@ -151,8 +151,8 @@ int64_t oc_num_kitchens(const oc_engine *e);
 int oc_obs_shape(const oc_engine *e, int64_t shape5[5]);   /* P, N, W, H, C */
 int oc_device_id(const oc_engine *e);
 
-/* Launch tuning (performance only, results never change): kitchens per wavefront group (4..64,
- * multiple of 4), 64-tile staging passes per flush (1..8), persistent wavefronts per CU (1..32).
+/* Launch tuning (performance only, results never change): kitchens per wavefront group (1..64;
+ * kitchens*tiles must be a multiple of 4, so any multiple of 4 works), 64-tile staging passes per flush (1..8), persistent wavefronts per CU (1..32).
  * 0 keeps the current value. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
 

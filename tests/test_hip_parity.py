@@ -106,7 +106,7 @@ def test_hip_vs_oracle_batch(layout, layout_params):
     eng.close()
 
 
-@pytest.mark.parametrize("kpw,passes,wpc", [(4, 1, 1), (8, 2, 4), (16, 4, 8), (32, 8, 2), (40, 3, 3), (12, 5, 16), (16, 2, 32)])
+@pytest.mark.parametrize("kpw,passes,wpc", [(4, 1, 1), (1, 1, 32), (8, 2, 4), (16, 4, 8), (32, 8, 2), (40, 3, 3), (12, 5, 16), (16, 2, 32)])
 def test_tuning_does_not_change_results(kpw, passes, wpc, layout_params):
     params = layout_params["random1"]            # S = 25: odd record padding, non-16B kitchen planes
     n, T = 1003, 230
