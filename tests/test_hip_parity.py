@@ -106,7 +106,7 @@ def test_hip_vs_oracle_batch(layout, layout_params):
     eng.close()
 
 
-@pytest.mark.parametrize("kpw,passes,wpc", [(4, 1, 1), (1, 1, 32), (8, 2, 4), (16, 4, 8), (32, 8, 2), (40, 3, 3), (12, 5, 16), (16, 2, 32)])
+@pytest.mark.parametrize("kpw,passes,wpc", [(4, 1, 1), (8, 2, 4), (16, 4, 8), (32, 8, 2), (40, 3, 3), (12, 5, 16), (16, 2, 32)])
 def test_tuning_does_not_change_results(kpw, passes, wpc, layout_params):
     params = layout_params["random1"]            # S = 25: odd record padding, non-16B kitchen planes
     n, T = 1003, 230
@@ -124,6 +124,27 @@ def test_tuning_does_not_change_results(kpw, passes, wpc, layout_params):
     for x, y in zip(eng.get_state(), ora.get_state()):
         assert np.array_equal(x, y)
     eng.close()
+
+
+def test_one_wave_per_kitchen_geometry(layout_params):
+    """kitchens_per_wave = 1 (the north star's first sketch, kept as a measurable geometry) is as exact as any."""
+    from diverse_conventions_amd.native import OvercookedNativeError
+    params = layout_params["simple"]
+    n, T = 301, 205
+    acts = _mixed_actions("simple", T, n, seed=77)
+    ora = oracle.OracleVecEnv(params, n)
+    eng = _engine(params, n)
+    eng.set_tuning(1, 1, 32)
+    dacts = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        obs, rew, done = eng.step(dacts[t])
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew), t
+    eng.close()
+    odd = _engine(layout_params["random1"], 8)            # S = 25: groups of 1 kitchen would start on 4-byte boundaries
+    with pytest.raises(OvercookedNativeError):
+        odd.set_tuning(1, 1, 8)
+    odd.close()
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 63, 64, 65])
