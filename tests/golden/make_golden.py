@@ -31,6 +31,9 @@ sys.dont_write_bytecode = True
 
 LAYOUTS = ["simple", "unident_s", "random1", "random0", "random3", "mdp_test", "simple_tomato",
            "corridor", "scenario2_s"]
+# this repo's own layout files (reference format): per-ingredient cook times / values, six pots, shaped
+# rewards, a 3x4 grid and a 16x5 hall -- paths none of the reference's shipped layouts exercise
+CUSTOM = ["six_pots", "tiny_mixed", "wide_hall"]
 CLASSIC = ["simple", "unident_s", "random1", "random0", "random3"]
 
 
@@ -104,7 +107,11 @@ def wh_obs(env, state):
 
 
 # ----------------------------------------------------------------------------- rollout recorder
+LAYOUT_PATHS = {}
+
+
 def rollout(oenv, omdp, layout, actions, init=None, horizon=200):
+    layout = LAYOUT_PATHS.get(layout, layout)
     """Steps the reference single env with the vector-wrapper reset rule
     (reference pantheonrl_extension/vectorenv.py:369-370): on done, n_reset() and hand out the
     reset observation while keeping the terminal reward / done."""
@@ -145,7 +152,7 @@ def guided_actions(oenv, omdp, layout, T, seed, eps=0.25, horizon=200):
     with eps-uniform noise so counters / collisions / useless interacts are exercised too.
     Produces the action stream; the reference MDP is the simulator it plans against."""
     rng = np.random.default_rng(seed)
-    env = oenv.SimplifiedOvercooked(layout, horizon=horizon)
+    env = oenv.SimplifiedOvercooked(LAYOUT_PATHS.get(layout, layout), horizon=horizon)
     mdp = env.mdp
     W, S = mdp.width, mdp.size
     terr = list(mdp.terrain_mtx)
@@ -232,8 +239,10 @@ def main():
 
     # 1) layout parameters --------------------------------------------------
     params = {}
-    for name in LAYOUTS:
-        d = oenv.get_base_layout_params(name, 200)
+    custom_path = {n: os.path.join(HERE, "layouts", n + ".layout") for n in CUSTOM}
+    LAYOUT_PATHS.update(custom_path)
+    for name in LAYOUTS + CUSTOM:
+        d = oenv.get_base_layout_params(custom_path.get(name, name), 200)
         params[name] = {k: (list(map(int, v)) if isinstance(v, (list, tuple)) else int(v)) for k, v in d.items()}
     with open(os.path.join(HERE, "layout_params.json"), "w") as f:
         json.dump(params, f, indent=1, sort_keys=True)
@@ -241,7 +250,7 @@ def main():
 
     # 2)+6) per-layout rollouts: uniform random (1000 steps, SURVEY 8(c) hash) and guided (600 steps)
     hashes = {}
-    for name in LAYOUTS:
+    for name in LAYOUTS + CUSTOM:
         P = params[name]["num_players"]
         rng = np.random.default_rng(0)
         acts = np.stack([rng.integers(0, 6, size=P) for _ in range(1000)]).astype(np.int32)
@@ -274,7 +283,7 @@ def main():
 
     # 4)+5) micro known-answer cases: explicit start states, 1-3 steps each.
     def st(layout, tiles=None, players=None, timestep=0):
-        env = oenv.SimplifiedOvercooked(layout)
+        env = oenv.SimplifiedOvercooked(LAYOUT_PATHS.get(layout, layout))
         t, p, ts = dump_state(env.state)
         t = t.copy(); p = p.copy()
         for pos, tup in (tiles or {}).items():
@@ -333,7 +342,7 @@ def main():
     # fuzz: arbitrary (also unreachable) states x one random joint action each.  Objects of any kind on any
     # tile, soups with any ingredient count / tick (cooking soups on counters, idle full soups, foreign
     # objects in pots), players anywhere walkable incl. the same tile, any held object, any timestep.
-    for name in ("simple", "unident_s", "mdp_test", "random0"):
+    for name in ("simple", "unident_s", "mdp_test", "random0", "six_pots", "tiny_mixed"):
         prm = params[name]
         S = prm["width"] * prm["height"]
         air = [i for i, t in enumerate(prm["terrain"]) if t == 0]

@@ -81,7 +81,11 @@ def test_python_wrapper_fails_loudly_without_gpu():
     assert e.value.status == -4
 
 
-@pytest.mark.parametrize("name", [n for n in layout_names() if get_base_layout_params(n, 200)["num_players"] == 2])
+CUSTOM = [os.path.join(ROOT, "tests", "golden", "layouts", n + ".layout") for n in ("six_pots", "tiny_mixed", "wide_hall")]
+
+
+@pytest.mark.parametrize("name", [n for n in layout_names() if get_base_layout_params(n, 200)["num_players"] == 2] + CUSTOM,
+                         ids=lambda n: os.path.basename(n).replace(".layout", ""))
 def test_per_engine_kernel_build_compiles_for_gfx950(name):
     size = native.jit_compile_check(get_base_layout_params(name, 200), arch="gfx950")
     assert size > 10_000

@@ -81,7 +81,7 @@ def _mixed_actions(layout, T, n, seed, p_guided=0.85):
 
 
 @pytest.mark.parametrize("layout", ["simple", "unident_s", "random1", "random0", "random3", "mdp_test",
-                                    "simple_tomato", "corridor", "scenario2_s"])
+                                    "simple_tomato", "corridor", "scenario2_s", "six_pots", "tiny_mixed", "wide_hall"])
 def test_hip_vs_oracle_batch(layout, layout_params):
     """4099 kitchens (ragged last wave), 450 steps crossing two horizon resets."""
     params = layout_params[layout]

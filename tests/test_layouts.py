@@ -6,9 +6,14 @@ from diverse_conventions_amd import ALIASES, CLASSIC_LAYOUTS, get_base_layout_pa
 
 
 def test_matches_reference_parser(layout_params):
+    import os
+    from conftest import GOLDEN
     for name, want in layout_params.items():
-        assert get_base_layout_params(name, 200) == want, name
-        assert get_base_layout_params(name, 77)["horizon"] == 77
+        custom = os.path.join(GOLDEN, "layouts", name + ".layout")     # this repo's own reference-format files
+        arg = custom if os.path.exists(custom) else name
+        assert get_base_layout_params(arg, 200) == want, name
+        assert get_base_layout_params(arg, 77)["horizon"] == 77
+    assert layout_params["six_pots"]["recipe_times"][4 * 2 + 1] == 11 and layout_params["six_pots"]["dish_pickup_rew"] == 7
 
 
 def test_all_21_reference_layouts_present():
