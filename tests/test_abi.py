@@ -89,3 +89,27 @@ CUSTOM = [os.path.join(ROOT, "tests", "golden", "layouts", n + ".layout") for n 
 def test_per_engine_kernel_build_compiles_for_gfx950(name):
     size = native.jit_compile_check(get_base_layout_params(name, 200), arch="gfx950")
     assert size > 10_000
+
+
+def test_plain_c_client_links_and_gets_error_codes(tmp_path):
+    """The boundary is a C ABI: a C99 translation unit includes the header, links the library and gets
+    status codes + messages (no exceptions, no torch types)."""
+    import subprocess
+    src = tmp_path / "client.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "overcooked_hip.h"
+int main(void) {
+    oc_layout_params p; oc_engine *e = NULL; int rc;
+    memset(&p, 0, sizeof p);
+    rc = oc_create(&p, 4, 0, &e);                       /* zeroed params: rejected, not crashed */
+    printf("%d|%s|%d|%lld\n", rc, oc_last_error(), oc_abi_version(), (long long)oc_num_kitchens(NULL));
+    return rc == OC_ERR_UNSUPPORTED ? 0 : 1;
+}''')
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(native.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
+    assert out[0] == "-2" and "2-player" in out[1] and out[2] == "1" and out[3] == "0"
