@@ -167,6 +167,13 @@ struct StepArgs {
     unsigned long long delta_pack;  // signed bytes {-W, +W, +1, -1, 0, 0}: tile-index delta per direction/action
     int32_t uniform_time;       // recipe time if all 16 are equal, else -1
     uint32_t start_posor;       // p0.pos | NORTH<<8 | p1.pos<<16 | NORTH<<24   (ref:387-391)
+    // fused multi-step rollout (FUSED kernels only): every wave keeps its kitchens' state in LDS for n_steps
+    // steps; step t reads action slice (t % tape_steps) or draws actions from the counter hash (actions == NULL)
+    int32_t n_steps, tape_steps;
+    int64_t action_step_stride; // elements between consecutive tape slices (= P*N)
+    int64_t obs_step_stride;    // bytes added to obs per step (0 = overwrite in place)
+    int64_t reward_step_stride, done_step_stride;   // elements
+    uint32_t rng_seed, rng_t0;  // hash RNG: action = hash(seed, kitchen, rng_t0 + t, player) % 6
     int32_t ablate;             // timing diagnostics only (env OC_ABLATE at oc_create); 0 in production
     unsigned long long *trace;  // timing diagnostics only: [wave][8] s_memrealtime stamps (100 MHz), else NULL
 };
@@ -270,6 +277,14 @@ __device__ __forceinline__ int load_action(const void *actions, int64_t idx) {
     if (ACT64) return static_cast<int>(reinterpret_cast<const long long *>(actions)[idx]);
     return reinterpret_cast<const int *>(actions)[idx];
 }
+// Counter-based action stream for synthetic rollouts: a pure function of (seed, kitchen, step,
+// player), so the CPU oracle can be fed the identical stream (tests replicate it in numpy).
+__host__ __device__ inline uint32_t oc_hash_action(uint32_t seed, uint32_t kitchen, uint32_t t, uint32_t player) {
+    uint32_t x = seed ^ (kitchen * 0x9E3779B1u) ^ (t * 0x85EBCA77u) ^ (player * 0xC2B2AE3Du);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return static_cast<uint32_t>((static_cast<unsigned long long>(x) * 6ull) >> 32);
+}
+
 __device__ __forceinline__ int sanitize_action(int a) {
     return (static_cast<unsigned>(a) > 5u) ? A_STAY : a;   // out-of-range codes behave as STAY
 }
@@ -304,7 +319,7 @@ __device__ __forceinline__ uint32_t held_flags(uint32_t held) {
 
 // One launch = one env step for every kitchen (STEP) or a pure featurisation of the given
 // state block (!STEP).  VEC16: every viewer plane base is 16-byte aligned.
-template <bool STEP, bool ACT64, bool VEC16, int QN, bool NT = false>
+template <bool STEP, bool ACT64, bool VEC16, int QN, bool NT = false, bool FUSED = false>
 __device__ __forceinline__ void step_body(const StepArgs &a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const LdsView L = carve(lds, a);
@@ -324,8 +339,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         for (int q = 0; q < QN; ++q) pre[q] = a.state[min(c0 + q * kWave, last_chunk)];
         if (STEP) {
             const int64_t kid = min(k0 + lane, KP_n_kitchens(a) - 1);
-            pa0 = load_action<ACT64>(a.actions, kid);
-            pa1 = load_action<ACT64>(a.actions, KP_n_kitchens(a) + kid);
+            if (FUSED && !a.actions) {
+                pa0 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0, 0));
+                pa1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0, 1));
+            } else {
+                pa0 = load_action<ACT64>(a.actions, kid);
+                pa1 = load_action<ACT64>(a.actions, KP_n_kitchens(a) + kid);
+            }
         } else {
             pa0 = pa1 = A_STAY;
         }
@@ -389,10 +409,31 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
                 uint32_t *d = L.state + loff[q];
                 d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
             }
-        const int a0 = sanitize_action(pa0), a1 = sanitize_action(pa1);
+        int raw0 = pa0, raw1 = pa1;
         prefetch(min(group + static_cast<int>(gridDim.x), KP_n_groups(a) - 1));     // last iteration: harmless re-read
         wave_sync();
         if (KP_trace(a) && stamp[6] == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
+        const int64_t plane_base = k0 * S * kChannels;   // byte offset of this group's kitchens in a viewer plane
+        const int ntiles = n_valid * S;
+        const int npass = (ntiles + tpp - 1) / tpp;
+
+      // FUSED: the whole rollout of this group happens here, its state never leaves LDS between steps
+      for (int step = 0; step < (FUSED ? a.n_steps : 1); ++step) {
+        const int a0 = sanitize_action(raw0), a1 = sanitize_action(raw1);
+        int8_t *const obs_t = a.obs + (FUSED ? step * a.obs_step_stride : 0);
+        int32_t *const reward_t = a.reward + (FUSED ? step * a.reward_step_stride : 0);
+        int32_t *const done_t = a.done + (FUSED ? step * a.done_step_stride : 0);
+        if (FUSED && step + 1 < a.n_steps) {             // next step's actions, in flight during this step
+            const int64_t kid = min(k0 + lane, KP_n_kitchens(a) - 1);
+            if (!a.actions) {
+                raw0 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 0));
+                raw1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 1));
+            } else {
+                const int64_t slice = static_cast<int64_t>((step + 1) % a.tape_steps) * a.action_step_stride;
+                raw0 = load_action<ACT64>(a.actions, slice + kid);
+                raw1 = load_action<ACT64>(a.actions, slice + KP_n_kitchens(a) + kid);
+            }
+        }
 
         // ---- phase T: lane = kitchen.  ref:381-385 get_state_transition + wrappers' done/reset rule
         if (lane < n_valid) {
@@ -446,9 +487,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
                 posor = pos0 | (or0 << 8) | (pos1 << 16) | (static_cast<uint32_t>(or1) << 24);
                 if (is_done) { posor = KP_start_posor(a); h0 = 0; h1 = 0; ts = 0; }
                 rec[S] = posor; rec[S + 1] = h0; rec[S + 2] = h1; rec[S + 3] = static_cast<uint32_t>(ts);
-                a.reward[kid] = rew;                     // envs/overcooked2_env.py:336-339: sum, to every player
-                a.reward[KP_n_kitchens(a) + kid] = rew;
-                a.done[kid] = static_cast<int32_t>(is_done);
+                reward_t[kid] = rew;                     // envs/overcooked2_env.py:336-339: sum, to every player
+                reward_t[KP_n_kitchens(a) + kid] = rew;
+                done_t[kid] = static_cast<int32_t>(is_done);
             }
             // per-kitchen values every tile lane of phase E needs, computed once here
             uint32_t *kd = L.kd + lane * kKd;
@@ -462,10 +503,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         if (KP_trace(a) && stamp[2] == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();
 
         // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
-        const int ntiles = n_valid * S;
-        const int npass = (ntiles + tpp - 1) / tpp;
         int k = k_first, o = o_first;
-        const int64_t plane_base = k0 * S * kChannels;   // byte offset of this group's kitchens in a viewer plane
         // One tile of phase E is split in two so that two tiles per lane can be in flight: all LDS
         // reads of both tiles are issued before either tile's arithmetic (the kernel runs at 1-2 waves
         // per SIMD, so instruction-level parallelism inside the wave is what hides LDS latency).
@@ -539,7 +577,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 if (KP_ablate(a) & 2) break;
-                int8_t *dst = a.obs + v * a.obs_player_stride + goff;
+                int8_t *dst = obs_t + v * a.obs_player_stride + goff;
                 const uint32_t *src = L.stage[v];
                 if (VEC16) {
                     const int nfull = gbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
@@ -555,7 +593,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         // tiles are encoded (latency cover) and before this group's first plane store is issued
         encode_passes(0);
         wave_sync();
-        land_prefetch();
+        if (!FUSED || step == 0) land_prefetch();
         flush_passes(0);
         wave_sync();
         if (KP_trace(a) && stamp[3] == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
@@ -568,6 +606,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
             flush_passes(p0);
             wave_sync();
         }
+
+      }   // step loop
 
         if (KP_trace(a) && stamp[4] == 0) stamp[4] = __builtin_amdgcn_s_memrealtime();
         // ---- state block LDS -> HBM
@@ -593,6 +633,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
 #ifndef OC_JIT
 template <bool STEP, bool ACT64, bool VEC16, int QN>
 __global__ __launch_bounds__(kWave) void oc_step_kernel(const StepArgs a) { step_body<STEP, ACT64, VEC16, QN>(a); }
+template <bool ACT64, bool VEC16, int QN>
+__global__ __launch_bounds__(kWave) void oc_rollout_kernel(const StepArgs a) { step_body<true, ACT64, VEC16, QN, false, true>(a); }
 #endif
 
 }  // namespace oc_dev
@@ -601,6 +643,12 @@ __global__ __launch_bounds__(kWave) void oc_step_kernel(const StepArgs a) { step
 // entry points of the per-engine build (looked up by name through hipModuleGetFunction)
 #define OC_JIT_ENTRY(name, STEP, ACT64, VEC16, NT) \
     extern "C" __global__ __launch_bounds__(64, OC_MIN_WAVES) void name(const oc_dev::StepArgs a) { oc_dev::step_body<STEP, ACT64, VEC16, OC_QN, NT>(a); }
+#define OC_JIT_ROLLOUT(name, ACT64, NT) \
+    extern "C" __global__ __launch_bounds__(64, OC_MIN_WAVES) void name(const oc_dev::StepArgs a) { oc_dev::step_body<true, ACT64, true, OC_QN, NT, true>(a); }
+OC_JIT_ROLLOUT(oc_jit_rollout_i32, false, false)
+OC_JIT_ROLLOUT(oc_jit_rollout_i64, true, false)
+OC_JIT_ROLLOUT(oc_jit_rollout_i32_nt, false, true)
+OC_JIT_ROLLOUT(oc_jit_rollout_i64_nt, true, true)
 OC_JIT_ENTRY(oc_jit_step_i32_v16, true, false, true, false)
 OC_JIT_ENTRY(oc_jit_step_i64_v16, true, true, true, false)
 OC_JIT_ENTRY(oc_jit_step_i32_v16_nt, true, false, true, true)

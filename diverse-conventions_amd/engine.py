@@ -176,6 +176,45 @@ class OvercookedEngine:
                                         _ptr(done), sd, self._stream()))
         return obs, reward, done
 
+    def rollout_fused(self, steps, actions=None, seed=0, t0=0, obs=None, reward=None, done=None):
+        """The whole rollout in one launch (state stays on chip between steps).  actions: tape [T_act, P, N]
+        used cyclically, or None for the built-in counter-hash stream (`synthetic_actions` reproduces it).
+        obs/reward/done may carry a leading time axis of length `steps` (filled slot by slot) or be single-step
+        buffers (overwritten every step)."""
+        flat, dt, t_act = None, native.OC_ACT_I32, 1
+        if actions is not None:
+            flat = actions if actions.device == self.device else actions.to(self.device)
+            if flat.dtype not in (torch.int32, torch.int64):
+                flat = flat.to(torch.int32)
+            flat = flat.contiguous()
+            if flat.dim() < 3 or flat[0].numel() != 2 * self.num_kitchens:
+                raise ValueError("rollout actions must be [T_act, P, N]")
+            dt, t_act = (native.OC_ACT_I64 if flat.dtype == torch.int64 else native.OC_ACT_I32), flat.shape[0]
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        done = self.done if done is None else done
+        so = obs[0].numel() if obs.dim() == 6 else 0
+        sr = reward[0].numel() if reward.dim() == 3 else 0
+        sd = done[0].numel() if done.dim() == 2 else 0
+        native.check(self._L.oc_rollout_fused(self._handle, _ptr(flat) if flat is not None else None, dt, t_act, steps,
+                                              seed & 0xFFFFFFFF, t0 & 0xFFFFFFFF, _ptr(obs), so, _ptr(reward), sr,
+                                              _ptr(done), sd, self._stream()))
+        return obs, reward, done
+
+    @staticmethod
+    def synthetic_actions(seed, num_kitchens, t0, steps):
+        """numpy int32 [steps, P, N]: the counter-hash stream `rollout_fused(actions=None)` plays."""
+        k = np.arange(num_kitchens, dtype=np.uint64)[None, None, :]
+        t = (np.arange(steps, dtype=np.uint64) + np.uint64(t0))[:, None, None]
+        p = np.arange(2, dtype=np.uint64)[None, :, None]
+        m = np.uint64(0xFFFFFFFF)
+        x = (np.uint64(seed & 0xFFFFFFFF) ^ ((k * np.uint64(0x9E3779B1)) & m) ^ ((t * np.uint64(0x85EBCA77)) & m)
+             ^ ((p * np.uint64(0xC2B2AE3D)) & m))
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & m
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & m
+        x ^= x >> np.uint64(16)
+        return ((x * np.uint64(6)) >> np.uint64(32)).astype(np.int32)
+
     def rollout_timed(self, actions, steps):
         """-> milliseconds between hipEvents bracketing `steps` step launches (synchronises)."""
         flat = actions.contiguous()

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", 
 
 # every symbol include/overcooked_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed",
+    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_gae_returns", "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
@@ -91,6 +91,10 @@ def lib():
     L.oc_episode_control.argtypes = [vp, vp, vp, vp]
     L.oc_rollout.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, i64, vp]
     L.oc_rollout_timed.argtypes = [vp, vp, i32, i64, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    u32 = ctypes.c_uint32
+    L.oc_rollout_fused.argtypes = [vp, vp, i32, i64, i64, u32, u32, vp, i64, vp, i64, vp, i64, vp]
+    L.oc_synthetic_action.argtypes = [u32, u32, u32, u32]
+    L.oc_synthetic_action.restype = u32
     L.oc_encode_states.argtypes = [vp, vp, i64, vp, vp]
     L.oc_encode_states_strided.argtypes = [vp, vp, i64, vp, i64, vp]
     L.oc_state_record_bytes.argtypes = [vp]

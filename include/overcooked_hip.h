@@ -118,6 +118,19 @@ int oc_rollout(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_
 int oc_rollout_timed(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T,
                      int8_t *d_obs, int32_t *d_reward, int32_t *d_done, void *stream, float *elapsed_ms);
 
+/* Whole rollout in ONE launch, for action streams that are known in advance (synthetic benchmarks, scripted or
+ * replayed tapes; a policy in the loop needs oc_step).  Kitchens never interact, so each wavefront keeps its
+ * kitchens' state in LDS for all T steps: no per-step launch boundary, no per-step state round trip through
+ * HBM, and step t's plane stores drain while step t+1 is computed.  Outputs for step t go to
+ * base + t * *_step_stride (obs stride in bytes, reward/done in elements; 0 = overwrite in place).
+ * d_actions: tape [T_act][P][N] used cyclically, or NULL for the built-in counter-hash stream
+ * action = oc_synthetic_action(rng_seed, kitchen, rng_t0 + t, player) (uniform on 0..5).
+ * Results are identical to T calls of oc_step with the same actions. */
+int oc_rollout_fused(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T, uint32_t rng_seed,
+                     uint32_t rng_t0, int8_t *d_obs, int64_t obs_step_stride, int32_t *d_reward, int64_t reward_step_stride,
+                     int32_t *d_done, int64_t done_step_stride, void *stream);
+uint32_t oc_synthetic_action(uint32_t seed, uint32_t kitchen, uint32_t step, uint32_t player);
+
 /* Featurise n externally supplied state records (device pointer, record format above) without
  * touching the engine's own kitchens: the receive side of a compact trajectory exchange. */
 int oc_encode_states(oc_engine *e, const void *d_states, int64_t n, int8_t *d_obs, void *stream);

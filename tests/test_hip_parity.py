@@ -314,3 +314,38 @@ def test_episode_control_masked_reset_and_stagger(layout_params):
         assert np.array_equal(x, y)
     assert max(dones_per_step[:39]) <= 6 and sum(dones_per_step) > n // 2   # resets arrive a few at a time, every step
     eng.close()
+
+
+@pytest.mark.parametrize("layout,n", [("simple", 1000), ("random1", 517), ("unident_s", 300), ("six_pots", 257)])
+def test_fused_rollout_equals_stepwise(layout, n, layout_params):
+    """oc_rollout_fused (whole rollout in one launch, state kept on chip) vs the oracle stepped on the same
+    actions: action tape (cyclic, int64) into time-major buffers, then the built-in counter-hash stream."""
+    from diverse_conventions_amd import OvercookedEngine
+    params = layout_params[layout]
+    T = 215
+    tape = _mixed_actions(layout, 60, n, seed=3)                     # shorter than T: used cyclically
+    ora = oracle.OracleVecEnv(params, n, nthreads=4)
+    eng = _engine(params, n)
+    obs = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    eng.rollout_fused(T, actions=torch.from_numpy(tape).cuda().to(torch.int64), obs=obs, reward=rew, done=done)
+    for t in range(T):
+        oobs, orew, odone = ora.step(tape[t % 60])
+        assert np.array_equal(obs[t].cpu().numpy(), oobs), t
+        assert np.array_equal(rew[t].cpu().numpy(), orew) and np.array_equal(done[t].cpu().numpy(), odone), t
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    # hash stream, outputs overwritten in place, continuing from the state above with a step offset
+    acts = OvercookedEngine.synthetic_actions(99, n, 1000, 37)
+    eng.rollout_fused(37, seed=99, t0=1000)
+    for t in range(37):
+        oobs, orew, odone = ora.step(acts[t])
+    assert np.array_equal(eng.obs.cpu().numpy(), oobs) and np.array_equal(eng.reward.cpu().numpy(), orew)
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    # and ordinary steps continue seamlessly afterwards
+    o2, r2, d2 = eng.step(torch.from_numpy(tape[0]).cuda())
+    oo, orr, od = ora.step(tape[0])
+    assert np.array_equal(o2.cpu().numpy(), oo) and np.array_equal(r2.cpu().numpy(), orr)
+    eng.close()
