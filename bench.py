@@ -158,16 +158,16 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     fused_ms = ev0.elapsed_time(ev1)
+    stats = torch.tensor([wall, kernel_ms, fused_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    wall, kernel_ms, fused_ms = float(stats[0]), float(stats[1]), float(stats[2])
     fused_bytes = n * (2 * S * 20 + 8 + 8 + 4)            # obs + i32 actions + reward + done; no state round trip
     fused = {"what": "same steps as one launch (state resident in LDS), action tape in HBM, outputs in place",
              "us_per_step": fused_ms * 1e3 / args.steps, "value": 2 * n * world * args.steps / (fused_ms / 1e3),
              "unit": "agent-env steps/s", "bytes_per_step": fused_bytes,
              "achieved_GBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9,
              "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
-    stats = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    wall, kernel_ms = float(stats[0]), float(stats[1])
 
     build_info = eng.kernel_build_info
     if rank == 0:
