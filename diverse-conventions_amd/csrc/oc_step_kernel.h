@@ -417,197 +417,197 @@ __device__ __forceinline__ void step_body(const StepArgs &a) {
         const int ntiles = n_valid * S;
         const int npass = (ntiles + tpp - 1) / tpp;
 
-      // FUSED: the whole rollout of this group happens here, its state never leaves LDS between steps
-      for (int step = 0; step < (FUSED ? a.n_steps : 1); ++step) {
-        const int a0 = sanitize_action(raw0), a1 = sanitize_action(raw1);
-        int8_t *const obs_t = a.obs + (FUSED ? step * a.obs_step_stride : 0);
-        int32_t *const reward_t = a.reward + (FUSED ? step * a.reward_step_stride : 0);
-        int32_t *const done_t = a.done + (FUSED ? step * a.done_step_stride : 0);
-        if (FUSED && step + 1 < a.n_steps) {             // next step's actions, in flight during this step
-            const int64_t kid = min(k0 + lane, KP_n_kitchens(a) - 1);
-            if (!a.actions) {
-                raw0 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 0));
-                raw1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 1));
-            } else {
-                const int64_t slice = static_cast<int64_t>((step + 1) % a.tape_steps) * a.action_step_stride;
-                raw0 = load_action<ACT64>(a.actions, slice + kid);
-                raw1 = load_action<ACT64>(a.actions, slice + KP_n_kitchens(a) + kid);
-            }
-        }
-
-        // ---- phase T: lane = kitchen.  ref:381-385 get_state_transition + wrappers' done/reset rule
-        if (lane < n_valid) {
-            uint32_t *rec = L.state + lane * KP_lstride(a);
-            uint32_t posor = rec[S], h0 = rec[S + 1], h1 = rec[S + 2];
-            uint32_t is_done = 0;
-            if (STEP && !(KP_ablate(a) & 1)) {
-                const int64_t kid = k0 + lane;
-                int ts = static_cast<int>(rec[S + 3]);
-                int pos0 = posor & 0xff, or0 = (posor >> 8) & 0xff, pos1 = (posor >> 16) & 0xff, or1 = posor >> 24;
-
-                // round 1 of LDS reads happened above (posor, hands, timestep); round 2: everything whose
-                // address depends only on positions/orientations/actions, issued together
-                const int ipos0 = pos0 + dir_delta(or0, KP_delta_pack(a)), ipos1 = pos1 + dir_delta(or1, KP_delta_pack(a));
-                const int cand0 = pos0 + dir_delta(a0, KP_delta_pack(a)), cand1 = pos1 + dir_delta(a1, KP_delta_pack(a));   // STAY/INTERACT: delta 0
-                const uint32_t terr_i0 = L.terrain[ipos0], terr_i1 = L.terrain[ipos1];
-                const uint32_t terr_c0 = L.terrain[cand0], terr_c1 = L.terrain[cand1];
-                uint32_t tile0 = rec[ipos0], tile1 = rec[ipos1];
-                const int rv0 = L.rvalues[recipe_index(h0)], rv1 = L.rvalues[recipe_index(h1)];
-                // ref:272-281 get_pot_states, taken once before anybody acts (ref:302); the first four pots
-                // are read unconditionally (index 0 when absent) so the reads go out together
-                auto nonempty_pot = [](uint32_t o) {
-                    const int tick = static_cast<int32_t>(o) >> 24;
-                    const int n = static_cast<int>(((o >> 8) & 0xff) + ((o >> 16) & 0xff));
-                    return ((o & 0xff) != O_NONE && (tick >= 0 || n < 3)) ? 1 : 0;
-                };
-                const uint32_t po0 = rec[KP_pots4(a, 0)], po1 = rec[KP_pots4(a, 1)], po2 = rec[KP_pots4(a, 2)], po3 = rec[KP_pots4(a, 3)];
-                int pot_states = (KP_n_pots(a) > 0 ? nonempty_pot(po0) : 0) + (KP_n_pots(a) > 1 ? nonempty_pot(po1) : 0) +
-                                 (KP_n_pots(a) > 2 ? nonempty_pot(po2) : 0) + (KP_n_pots(a) > 3 ? nonempty_pot(po3) : 0);
-                for (int i = 4; i < KP_n_pots(a); ++i) pot_states += nonempty_pot(rec[L.pots[i]]);
-                if (KP_trace(a) && stamp[7] == 0) stamp[7] = __builtin_amdgcn_s_memrealtime() + (pot_states & 0) + (tile0 & 0) + (tile1 & 0) + (terr_c0 & 0) + (terr_c1 & 0);
-                // interacts in player order on pre-move positions; player 1 sees player 0's effects
-                int rew = interact(a0 == A_INTERACT, terr_i0, tile0, h0, h1, rv0, pot_states, rec, L, a);
-                rec[ipos0] = tile0;
-                if (ipos1 == ipos0) tile1 = tile0;
-                rew += interact(a1 == A_INTERACT, terr_i1, tile1, h1, h0, rv1, pot_states, rec, L, a);
-                rec[ipos1] = tile1;
-
-                if (KP_trace(a) && stamp[8] == 0) stamp[8] = __builtin_amdgcn_s_memrealtime() + (rew & 0);
-                // ref:393-399 _move_if_direction, ref:356-366 _handle_collisions
-                const int no0 = (a0 >= A_STAY) ? or0 : a0, no1 = (a1 >= A_STAY) ? or1 : a1;
-                const int np0 = (terr_c0 != T_AIR) ? pos0 : cand0;        // cand == pos (own, walkable tile) when not moving
-                const int np1 = (terr_c1 != T_AIR) ? pos1 : cand1;
-                const bool blocked = (np0 == np1) || (np0 == pos1 && pos0 == np1);
-                if (!blocked) { pos0 = np0; pos1 = np1; }
-                or0 = no0; or1 = no1;
-
-                // ref:373-375 timestep; envs/overcooked2_env.py:334 done; vectorenv.py:369-370 reset rule
-                ts += 1;
-                is_done = ts >= KP_horizon(a) ? 1u : 0u;
-                posor = pos0 | (or0 << 8) | (pos1 << 16) | (static_cast<uint32_t>(or1) << 24);
-                if (is_done) { posor = KP_start_posor(a); h0 = 0; h1 = 0; ts = 0; }
-                rec[S] = posor; rec[S + 1] = h0; rec[S + 2] = h1; rec[S + 3] = static_cast<uint32_t>(ts);
-                reward_t[kid] = rew;                     // envs/overcooked2_env.py:336-339: sum, to every player
-                reward_t[KP_n_kitchens(a) + kid] = rew;
-                done_t[kid] = static_cast<int32_t>(is_done);
-            }
-            // per-kitchen values every tile lane of phase E needs, computed once here
-            uint32_t *kd = L.kd + lane * kKd;
-            kd[0] = (posor & 0xff) | (((posor >> 16) & 0xff) << 8) | (is_done << 16);
-            kd[1] = 1u << (8 * ((posor >> 8) & 3));      // ref:221-234 orientation one-hot bytes, player 0
-            kd[2] = 1u << (8 * ((posor >> 24) & 3));     //                                       player 1
-            kd[3] = held_flags(h0);
-            kd[4] = held_flags(h1);
-        }
-        wave_sync();
-        if (KP_trace(a) && stamp[2] == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();
-
-        // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
-        int k = k_first, o = o_first;
-        // One tile of phase E is split in two so that two tiles per lane can be in flight: all LDS
-        // reads of both tiles are issued before either tile's arithmetic (the kernel runs at 1-2 waves
-        // per SIMD, so instruction-level parallelism inside the wave is what hides LDS latency).
-        struct TileIn { uint2 tab; uint4 kq; uint32_t hf1; uint32_t obj; uint32_t *cell; bool active; };
-        auto tile_read = [&](int kk, int oo, bool active) {
-            TileIn r;
-            kk = min(kk, KP_kpw(a) - 1);                     // idle lanes of a ragged last pass read in-range LDS
-            r.tab = KP_kpp(a) > 0 ? tab_fixed : L.out_tab2[oo];
-            r.kq = *reinterpret_cast<const uint4 *>(L.kd + kk * kKd);       // pp, oh0, oh1, hf0
-            r.hf1 = L.kd[kk * kKd + 4];
-            uint32_t *cell = L.state + kk * KP_lstride(a) + (r.tab.x & 0xff);
-            r.obj = *cell;
-            r.cell = active ? cell : L.dump;             // idle lanes store to a dump word instead of branching
-            r.active = active;
-            return r;
-        };
-        auto tile_encode = [&](const TileIn &r, int slot) {
-            const uint32_t t = r.tab.x & 0xff;
-            uint32_t obj = r.obj;
-            if (STEP) {
-                // ref:376-379: every SOUP lying on a tile that is cooking ticks (held ones do not)
-                const int tick = static_cast<int32_t>(obj) >> 24;
-                if ((obj & 0xff) == O_SOUP && tick >= 0 && tick < cook_time(L, a, obj)) obj += 0x01000000u;
-                if (r.kq.x & 0x10000u) obj = 0;          // kitchen was reset this step
-                *r.cell = obj;
-            }
-            const bool here0 = (r.kq.x & 0xff) == t, here1 = ((r.kq.x >> 8) & 0xff) == t;
-            const uint32_t A = here0 ? r.kq.y : 0u, B = here1 ? r.kq.z : 0u;      // ref:221-234 orientation one-hots
-            const uint32_t e0 = here0 ? 1u : 0u, e1 = here1 ? 1u : 0u;
-            const uint32_t hands = (here0 ? r.kq.w : 0u) | (here1 ? r.hf1 : 0u);  // ref:236-253 objects in hands
-            const uint32_t name = obj & 0xff;
-            const bool inpot = (name == O_SOUP) && (r.tab.x & 0x100u);
-            const int tk = static_cast<int32_t>(obj) >> 24;
-            // ref:182-211 objects lying on tiles
-            const uint32_t lying = inpot ? 0u : held_flags(obj);
-            const uint32_t d3 = r.tab.y | (inpot ? ((obj << 16) & 0xFF000000u) : 0u);      // ch15 = onions in the pot
-            const uint32_t d4 = (inpot ? static_cast<uint32_t>(max(tk, 0)) : 0u) | lying | hands;
-            const uint32_t thi = r.tab.x >> 16;          // terrain bits of channels 10,11 (ref:165-171)
-            uint32_t *s0 = r.active ? L.stage[0] + slot : L.dump, *s1 = r.active ? L.stage[1] + slot : L.dump + 8;
-            // bytes: [self here, other here, self orient x4, other orient x4, terrain ...]
-            s0[0] = e0 | (e1 << 8) | (A << 16); s0[1] = __builtin_amdgcn_alignbit(B, A, 16); s0[2] = __builtin_amdgcn_alignbit(thi, B, 16); s0[3] = d3; s0[4] = d4;
-            s1[0] = e1 | (e0 << 8) | (B << 16); s1[1] = __builtin_amdgcn_alignbit(A, B, 16); s1[2] = __builtin_amdgcn_alignbit(thi, A, 16); s1[3] = d3; s1[4] = d4;
-        };
-        auto advance = [&]() {
-            k += dk; o += dq;
-            if (o >= S) { o -= S; ++k; }
-        };
-        auto encode_passes = [&](int p0) {
-            const int pend = min(p0 + KP_gpasses(a), npass);
-            if (KP_ablate(a) & 4) return;
-            int p = p0;
-            for (; p + 1 < pend; p += 2) {               // two tiles per lane in flight
-                const int slot = ((p - p0) * tpp + lane) * kTileDwords;
-                const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
-                advance();
-                const TileIn r1 = tile_read(k, o, lane < tpp && (p + 1) * tpp + lane < ntiles);
-                advance();
-                tile_encode(r0, slot);
-                tile_encode(r1, slot + tpp * kTileDwords);
-            }
-            if (p < pend) {
-                const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
-                advance();
-                tile_encode(r0, ((p - p0) * tpp + lane) * kTileDwords);
-            }
-        };
-        auto flush_passes = [&](int p0) {
-            // ---- flush the staged tiles of both viewers: contiguous bytes in the output planes
-            const int gbytes = (min(ntiles - p0 * tpp, KP_gpasses(a) * tpp)) * kChannels;
-            const int64_t goff = plane_base + static_cast<int64_t>(p0) * tpp * kChannels;
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                if (KP_ablate(a) & 2) break;
-                int8_t *dst = obs_t + v * a.obs_player_stride + goff;
-                const uint32_t *src = L.stage[v];
-                if (VEC16) {
-                    const int nfull = gbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
-                    for (int c = lane; c < nfull; c += kWave) store16<NT>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
-                    const int rem = (gbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
-                    if (lane < rem) store4(dst + nfull * 16 + lane * 4, src[nfull * 4 + lane]);
+        // FUSED: the whole rollout of this group happens here, its state never leaves LDS between steps
+        for (int step = 0; step < (FUSED ? a.n_steps : 1); ++step) {
+            const int a0 = sanitize_action(raw0), a1 = sanitize_action(raw1);
+            int8_t *const obs_t = a.obs + (FUSED ? step * a.obs_step_stride : 0);
+            int32_t *const reward_t = a.reward + (FUSED ? step * a.reward_step_stride : 0);
+            int32_t *const done_t = a.done + (FUSED ? step * a.done_step_stride : 0);
+            if (FUSED && step + 1 < a.n_steps) {             // next step's actions, in flight during this step
+                const int64_t kid = min(k0 + lane, KP_n_kitchens(a) - 1);
+                if (!a.actions) {
+                    raw0 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 0));
+                    raw1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0 + step + 1, 1));
                 } else {
-                    for (int c = lane; c * 4 < gbytes; c += kWave) store4(dst + c * 4, src[c]);
+                    const int64_t slice = static_cast<int64_t>((step + 1) % a.tape_steps) * a.action_step_stride;
+                    raw0 = load_action<ACT64>(a.actions, slice + kid);
+                    raw1 = load_action<ACT64>(a.actions, slice + KP_n_kitchens(a) + kid);
                 }
             }
-        };
-        // first flush group peeled so that the prefetch lands at a fixed program point: after the first
-        // tiles are encoded (latency cover) and before this group's first plane store is issued
-        encode_passes(0);
-        wave_sync();
-        if (!FUSED || step == 0) land_prefetch();
-        flush_passes(0);
-        wave_sync();
-        if (KP_trace(a) && stamp[3] == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
+
+            // ---- phase T: lane = kitchen.  ref:381-385 get_state_transition + wrappers' done/reset rule
+            if (lane < n_valid) {
+                uint32_t *rec = L.state + lane * KP_lstride(a);
+                uint32_t posor = rec[S], h0 = rec[S + 1], h1 = rec[S + 2];
+                uint32_t is_done = 0;
+                if (STEP && !(KP_ablate(a) & 1)) {
+                    const int64_t kid = k0 + lane;
+                    int ts = static_cast<int>(rec[S + 3]);
+                    int pos0 = posor & 0xff, or0 = (posor >> 8) & 0xff, pos1 = (posor >> 16) & 0xff, or1 = posor >> 24;
+
+                    // round 1 of LDS reads happened above (posor, hands, timestep); round 2: everything whose
+                    // address depends only on positions/orientations/actions, issued together
+                    const int ipos0 = pos0 + dir_delta(or0, KP_delta_pack(a)), ipos1 = pos1 + dir_delta(or1, KP_delta_pack(a));
+                    const int cand0 = pos0 + dir_delta(a0, KP_delta_pack(a)), cand1 = pos1 + dir_delta(a1, KP_delta_pack(a));   // STAY/INTERACT: delta 0
+                    const uint32_t terr_i0 = L.terrain[ipos0], terr_i1 = L.terrain[ipos1];
+                    const uint32_t terr_c0 = L.terrain[cand0], terr_c1 = L.terrain[cand1];
+                    uint32_t tile0 = rec[ipos0], tile1 = rec[ipos1];
+                    const int rv0 = L.rvalues[recipe_index(h0)], rv1 = L.rvalues[recipe_index(h1)];
+                    // ref:272-281 get_pot_states, taken once before anybody acts (ref:302); the first four pots
+                    // are read unconditionally (index 0 when absent) so the reads go out together
+                    auto nonempty_pot = [](uint32_t o) {
+                        const int tick = static_cast<int32_t>(o) >> 24;
+                        const int n = static_cast<int>(((o >> 8) & 0xff) + ((o >> 16) & 0xff));
+                        return ((o & 0xff) != O_NONE && (tick >= 0 || n < 3)) ? 1 : 0;
+                    };
+                    const uint32_t po0 = rec[KP_pots4(a, 0)], po1 = rec[KP_pots4(a, 1)], po2 = rec[KP_pots4(a, 2)], po3 = rec[KP_pots4(a, 3)];
+                    int pot_states = (KP_n_pots(a) > 0 ? nonempty_pot(po0) : 0) + (KP_n_pots(a) > 1 ? nonempty_pot(po1) : 0) +
+                                     (KP_n_pots(a) > 2 ? nonempty_pot(po2) : 0) + (KP_n_pots(a) > 3 ? nonempty_pot(po3) : 0);
+                    for (int i = 4; i < KP_n_pots(a); ++i) pot_states += nonempty_pot(rec[L.pots[i]]);
+                    if (KP_trace(a) && stamp[7] == 0) stamp[7] = __builtin_amdgcn_s_memrealtime() + (pot_states & 0) + (tile0 & 0) + (tile1 & 0) + (terr_c0 & 0) + (terr_c1 & 0);
+                    // interacts in player order on pre-move positions; player 1 sees player 0's effects
+                    int rew = interact(a0 == A_INTERACT, terr_i0, tile0, h0, h1, rv0, pot_states, rec, L, a);
+                    rec[ipos0] = tile0;
+                    if (ipos1 == ipos0) tile1 = tile0;
+                    rew += interact(a1 == A_INTERACT, terr_i1, tile1, h1, h0, rv1, pot_states, rec, L, a);
+                    rec[ipos1] = tile1;
+
+                    if (KP_trace(a) && stamp[8] == 0) stamp[8] = __builtin_amdgcn_s_memrealtime() + (rew & 0);
+                    // ref:393-399 _move_if_direction, ref:356-366 _handle_collisions
+                    const int no0 = (a0 >= A_STAY) ? or0 : a0, no1 = (a1 >= A_STAY) ? or1 : a1;
+                    const int np0 = (terr_c0 != T_AIR) ? pos0 : cand0;        // cand == pos (own, walkable tile) when not moving
+                    const int np1 = (terr_c1 != T_AIR) ? pos1 : cand1;
+                    const bool blocked = (np0 == np1) || (np0 == pos1 && pos0 == np1);
+                    if (!blocked) { pos0 = np0; pos1 = np1; }
+                    or0 = no0; or1 = no1;
+
+                    // ref:373-375 timestep; envs/overcooked2_env.py:334 done; vectorenv.py:369-370 reset rule
+                    ts += 1;
+                    is_done = ts >= KP_horizon(a) ? 1u : 0u;
+                    posor = pos0 | (or0 << 8) | (pos1 << 16) | (static_cast<uint32_t>(or1) << 24);
+                    if (is_done) { posor = KP_start_posor(a); h0 = 0; h1 = 0; ts = 0; }
+                    rec[S] = posor; rec[S + 1] = h0; rec[S + 2] = h1; rec[S + 3] = static_cast<uint32_t>(ts);
+                    reward_t[kid] = rew;                     // envs/overcooked2_env.py:336-339: sum, to every player
+                    reward_t[KP_n_kitchens(a) + kid] = rew;
+                    done_t[kid] = static_cast<int32_t>(is_done);
+                }
+                // per-kitchen values every tile lane of phase E needs, computed once here
+                uint32_t *kd = L.kd + lane * kKd;
+                kd[0] = (posor & 0xff) | (((posor >> 16) & 0xff) << 8) | (is_done << 16);
+                kd[1] = 1u << (8 * ((posor >> 8) & 3));      // ref:221-234 orientation one-hot bytes, player 0
+                kd[2] = 1u << (8 * ((posor >> 24) & 3));     //                                       player 1
+                kd[3] = held_flags(h0);
+                kd[4] = held_flags(h1);
+            }
+            wave_sync();
+            if (KP_trace(a) && stamp[2] == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();
+
+            // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
+            int k = k_first, o = o_first;
+            // One tile of phase E is split in two so that two tiles per lane can be in flight: all LDS
+            // reads of both tiles are issued before either tile's arithmetic (the kernel runs at 1-2 waves
+            // per SIMD, so instruction-level parallelism inside the wave is what hides LDS latency).
+            struct TileIn { uint2 tab; uint4 kq; uint32_t hf1; uint32_t obj; uint32_t *cell; bool active; };
+            auto tile_read = [&](int kk, int oo, bool active) {
+                TileIn r;
+                kk = min(kk, KP_kpw(a) - 1);                     // idle lanes of a ragged last pass read in-range LDS
+                r.tab = KP_kpp(a) > 0 ? tab_fixed : L.out_tab2[oo];
+                r.kq = *reinterpret_cast<const uint4 *>(L.kd + kk * kKd);       // pp, oh0, oh1, hf0
+                r.hf1 = L.kd[kk * kKd + 4];
+                uint32_t *cell = L.state + kk * KP_lstride(a) + (r.tab.x & 0xff);
+                r.obj = *cell;
+                r.cell = active ? cell : L.dump;             // idle lanes store to a dump word instead of branching
+                r.active = active;
+                return r;
+            };
+            auto tile_encode = [&](const TileIn &r, int slot) {
+                const uint32_t t = r.tab.x & 0xff;
+                uint32_t obj = r.obj;
+                if (STEP) {
+                    // ref:376-379: every SOUP lying on a tile that is cooking ticks (held ones do not)
+                    const int tick = static_cast<int32_t>(obj) >> 24;
+                    if ((obj & 0xff) == O_SOUP && tick >= 0 && tick < cook_time(L, a, obj)) obj += 0x01000000u;
+                    if (r.kq.x & 0x10000u) obj = 0;          // kitchen was reset this step
+                    *r.cell = obj;
+                }
+                const bool here0 = (r.kq.x & 0xff) == t, here1 = ((r.kq.x >> 8) & 0xff) == t;
+                const uint32_t A = here0 ? r.kq.y : 0u, B = here1 ? r.kq.z : 0u;      // ref:221-234 orientation one-hots
+                const uint32_t e0 = here0 ? 1u : 0u, e1 = here1 ? 1u : 0u;
+                const uint32_t hands = (here0 ? r.kq.w : 0u) | (here1 ? r.hf1 : 0u);  // ref:236-253 objects in hands
+                const uint32_t name = obj & 0xff;
+                const bool inpot = (name == O_SOUP) && (r.tab.x & 0x100u);
+                const int tk = static_cast<int32_t>(obj) >> 24;
+                // ref:182-211 objects lying on tiles
+                const uint32_t lying = inpot ? 0u : held_flags(obj);
+                const uint32_t d3 = r.tab.y | (inpot ? ((obj << 16) & 0xFF000000u) : 0u);      // ch15 = onions in the pot
+                const uint32_t d4 = (inpot ? static_cast<uint32_t>(max(tk, 0)) : 0u) | lying | hands;
+                const uint32_t thi = r.tab.x >> 16;          // terrain bits of channels 10,11 (ref:165-171)
+                uint32_t *s0 = r.active ? L.stage[0] + slot : L.dump, *s1 = r.active ? L.stage[1] + slot : L.dump + 8;
+                // bytes: [self here, other here, self orient x4, other orient x4, terrain ...]
+                s0[0] = e0 | (e1 << 8) | (A << 16); s0[1] = __builtin_amdgcn_alignbit(B, A, 16); s0[2] = __builtin_amdgcn_alignbit(thi, B, 16); s0[3] = d3; s0[4] = d4;
+                s1[0] = e1 | (e0 << 8) | (B << 16); s1[1] = __builtin_amdgcn_alignbit(A, B, 16); s1[2] = __builtin_amdgcn_alignbit(thi, A, 16); s1[3] = d3; s1[4] = d4;
+            };
+            auto advance = [&]() {
+                k += dk; o += dq;
+                if (o >= S) { o -= S; ++k; }
+            };
+            auto encode_passes = [&](int p0) {
+                const int pend = min(p0 + KP_gpasses(a), npass);
+                if (KP_ablate(a) & 4) return;
+                int p = p0;
+                for (; p + 1 < pend; p += 2) {               // two tiles per lane in flight
+                    const int slot = ((p - p0) * tpp + lane) * kTileDwords;
+                    const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
+                    advance();
+                    const TileIn r1 = tile_read(k, o, lane < tpp && (p + 1) * tpp + lane < ntiles);
+                    advance();
+                    tile_encode(r0, slot);
+                    tile_encode(r1, slot + tpp * kTileDwords);
+                }
+                if (p < pend) {
+                    const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
+                    advance();
+                    tile_encode(r0, ((p - p0) * tpp + lane) * kTileDwords);
+                }
+            };
+            auto flush_passes = [&](int p0) {
+                // ---- flush the staged tiles of both viewers: contiguous bytes in the output planes
+                const int gbytes = (min(ntiles - p0 * tpp, KP_gpasses(a) * tpp)) * kChannels;
+                const int64_t goff = plane_base + static_cast<int64_t>(p0) * tpp * kChannels;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    if (KP_ablate(a) & 2) break;
+                    int8_t *dst = obs_t + v * a.obs_player_stride + goff;
+                    const uint32_t *src = L.stage[v];
+                    if (VEC16) {
+                        const int nfull = gbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
+                        for (int c = lane; c < nfull; c += kWave) store16<NT>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
+                        const int rem = (gbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
+                        if (lane < rem) store4(dst + nfull * 16 + lane * 4, src[nfull * 4 + lane]);
+                    } else {
+                        for (int c = lane; c * 4 < gbytes; c += kWave) store4(dst + c * 4, src[c]);
+                    }
+                }
+            };
+            // first flush group peeled so that the prefetch lands at a fixed program point: after the first
+            // tiles are encoded (latency cover) and before this group's first plane store is issued
+            encode_passes(0);
+            wave_sync();
+            if (!FUSED || step == 0) land_prefetch();
+            flush_passes(0);
+            wave_sync();
+            if (KP_trace(a) && stamp[3] == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
 #if defined(OC_NOUNROLL) && OC_NOUNROLL
 #pragma unroll 1
 #endif
-        for (int p0 = KP_gpasses(a); p0 < npass; p0 += KP_gpasses(a)) {
-            encode_passes(p0);
-            wave_sync();
-            flush_passes(p0);
-            wave_sync();
-        }
+            for (int p0 = KP_gpasses(a); p0 < npass; p0 += KP_gpasses(a)) {
+                encode_passes(p0);
+                wave_sync();
+                flush_passes(p0);
+                wave_sync();
+            }
 
-      }   // step loop
+        }   // step loop
 
         if (KP_trace(a) && stamp[4] == 0) stamp[4] = __builtin_amdgcn_s_memrealtime();
         // ---- state block LDS -> HBM
