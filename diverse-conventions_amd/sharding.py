@@ -105,3 +105,23 @@ class TrajectoryExchange:
         for r in range(world):
             engine.encode_states_into(records_all[r, t], out, r * n)
         return out
+
+
+def segment_scores(episode_returns: torch.Tensor, segments: List[Segment], group: Optional[dist.ProcessGroup] = None):
+    """Mean episode return per pairing segment over all ranks: the 2k+1 numbers the reference's score
+    bookkeeping needs per episode (`xp_scores`, `best_i`: train/XD/xd_player.py:143-149) -- the only other
+    collective of a sharded run, one all-reduce of 2(2k+1) floats.  episode_returns: [n_local] float."""
+    sums = torch.stack([episode_returns[s.start:s.stop].sum() for s in segments])
+    counts = torch.tensor([float(s.stop - s.start) for s in segments], device=episode_returns.device, dtype=sums.dtype)
+    packed = torch.cat([sums, counts])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(packed, group=group)
+    g = len(segments)
+    return packed[:g] / packed[g:]
+
+
+def best_partner(scores: torch.Tensor, n_conventions: int, xp_weight: float = 1.0) -> int:
+    """argmax_i of xp_weight * (mean XP0_i + mean XP1_i) (train/XD/xd_player.py:144-149)."""
+    k = n_conventions
+    both = xp_weight * (scores[1:1 + k] + scores[1 + k:1 + 2 * k])
+    return int(both.argmax())

@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diverse_conventions_amd.sharding import KitchenShard, TrajectoryExchange, local_segments, pairing_segments
+from diverse_conventions_amd.sharding import (KitchenShard, TrajectoryExchange, best_partner, local_segments, pairing_segments,
+                                              segment_scores)
 from diverse_conventions_amd.engine import pack_states, unpack_states
 
 
@@ -87,6 +88,14 @@ def _worker(rank, world, port, q):
         chk = oracle.OracleVecEnv(params, total)
         chk.set_state(tiles, players, ts)
         ok &= np.array_equal(chk.encode(), ref.encode())
+        # score bookkeeping: per-segment mean returns over both ranks == single-process means
+        segs = pairing_segments(2, 2)                                   # 5 segments of 2 kitchens per rank
+        torch.manual_seed(0)
+        full = torch.rand(2, 10, dtype=torch.float64)                   # [rank, kitchen]
+        got_scores = segment_scores(full[rank], segs)
+        want = torch.stack([full[:, sg.start:sg.stop].mean() for sg in segs])
+        ok &= bool(torch.allclose(got_scores, want))
+        ok &= best_partner(got_scores, 2) == int((want[1:3] + want[3:5]).argmax())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
