@@ -8,7 +8,10 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liboracle.so")
+# ORACLE_SANITIZE=1 runs the ASan/UBSan build of the oracle (CPU only; GPU sanitizers are not available on the pool):
+#   ORACLE_SANITIZE=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python -m pytest tests/test_oracle_golden.py
+SANITIZE = os.environ.get("ORACLE_SANITIZE", "0") not in ("", "0")
+LIB_PATH = os.path.join(HERE, "liboracle_asan.so" if SANITIZE else "liboracle.so")
 MAX_TILES, MAX_PLAYERS = 256, 8
 
 
@@ -26,7 +29,7 @@ class OcrLayout(ctypes.Structure):
 def build(force=False):
     src = os.path.join(HERE, "overcooked_oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", HERE, "-B", "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", HERE, "-B", os.path.basename(LIB_PATH)], check=True, stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

@@ -349,3 +349,30 @@ def test_fused_rollout_equals_stepwise(layout, n, layout_params):
     oo, orr, od = ora.step(tape[0])
     assert np.array_equal(o2.cpu().numpy(), oo) and np.array_equal(r2.cpu().numpy(), orr)
     eng.close()
+
+
+def test_no_stray_writes_around_any_output(layout_params):
+    """Every output lives inside a larger canary-filled allocation; after stepwise, C-loop and fused rollouts of a
+    ragged kitchen count only the exact output ranges may have changed (GPU sanitizers are unavailable on the pool)."""
+    params = layout_params["random0"]                 # S = 25: unpadded records are not 16-byte multiples
+    n, pad = 1237, 4096
+    eng = _engine(params, n)
+    acts = torch.from_numpy(_mixed_actions("random0", 40, n, seed=6)).cuda()
+
+    def guarded(shape, dtype, fill):
+        numel = int(np.prod(shape))
+        raw = torch.full((numel + 2 * pad,), fill, dtype=dtype, device="cuda")
+        return raw, raw[pad:pad + numel].view(shape)
+
+    raw_o, obs = guarded((3,) + tuple(eng.obs.shape), torch.int8, 0x55)
+    raw_r, rew = guarded((3, 2, n), torch.int32, 0x55555555)
+    raw_d, done = guarded((3, n), torch.int32, 0x55555555)
+    eng.step(acts[0], obs=obs[0], reward=rew[0], done=done[0])
+    eng.rollout(acts, 3, obs=obs, reward=rew, done=done)
+    eng.rollout_fused(3, actions=acts, obs=obs, reward=rew, done=done)
+    eng.rollout_fused(3, seed=5, obs=obs, reward=rew, done=done)
+    torch.cuda.synchronize()
+    for raw, fill in ((raw_o, 0x55), (raw_r, 0x55555555), (raw_d, 0x55555555)):
+        assert bool((raw[:pad] == fill).all()) and bool((raw[-pad:] == fill).all())
+    assert int((obs == 0x55).sum()) == 0               # and every byte inside was written (values are 0..20)
+    eng.close()
