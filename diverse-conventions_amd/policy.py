@@ -6,7 +6,8 @@ The reference evaluates every convention's actor separately and sequentially on 
 train/partner_agents.py:97-111).  `StackedActors` keeps K actors of the reference architecture
 (R_Actor = CNNBase + Categorical head: train/MAPPO/r_actor_critic.py:11-76, utils/cnn.py:12-60,
 utils/act.py, utils/distributions.py:60-80) with their weights stacked on a leading axis and evaluates all
-segments with four batched GEMMs, reading the engine's int8 observations directly.
+segments with four batched GEMMs, reading the engine's int8 observations directly (the 3x3 convolution is
+expanded once into a dense matrix over the flattened observation row, so there is no im2col pass).
 """
 from typing import List, Sequence
 
@@ -28,9 +29,18 @@ class StackedActors:
         assert (C, kw, kh) == (self.C, 3, 3)
         self.K, self.O = K, O
         self.P = (self.W - 2) * (self.H - 2)                                              # conv output positions
-        # conv as a GEMM on 3x3 patches: rows ordered (c, kx, ky) like weight.reshape(O, C*9)
-        self.w_conv = conv_w.reshape(K, O, C * 9).transpose(1, 2).contiguous()            # [K, C*9, O]
-        self.b_conv = torch.stack([t(sd, "base.cnn.cnn.0.bias") for sd in state_dicts])   # [K, O]
+        # The 3x3 valid convolution of a W x H x C grid is a (structured-sparse) linear map from the flattened
+        # observation row (W*H*C values, exactly the engine's memory layout) to (position, channel) outputs.
+        # Expanding it once into a dense [W*H*C, P*O] matrix turns the conv into ONE GEMM on the raw rows:
+        # no im2col / unfold (which writes and re-reads 9x the observation bytes), ~2x the MACs, far less traffic.
+        dense = torch.zeros((K, self.W, self.H, C, self.W - 2, self.H - 2, O), device=self.device, dtype=dtype)
+        for x in range(self.W - 2):
+            for y in range(self.H - 2):
+                # conv_w[k, o, c, kx, ky] multiplies input tile (x+kx, y+ky), channel c
+                dense[:, x:x + 3, y:y + 3, :, x, y, :] = conv_w.permute(0, 3, 4, 2, 1)
+        self.w_conv = dense.reshape(K, self.W * self.H * C, self.P * O).contiguous()      # [K, W*H*C, P*O], cols (p, o)
+        b = torch.stack([t(sd, "base.cnn.cnn.0.bias") for sd in state_dicts])             # [K, O]
+        self.b_conv = b.unsqueeze(1).expand(K, self.P, O).reshape(K, self.P * O).contiguous()
         fc1 = torch.stack([t(sd, "base.cnn.cnn.3.weight") for sd in state_dicts])         # [K, Hd, O*P], cols (o, p)
         Hd = fc1.shape[1]
         # our conv output is position-major (p, o); permute the columns once instead of transposing activations
@@ -41,22 +51,26 @@ class StackedActors:
         self.w_act = torch.stack([t(sd, "act.action_out.linear.weight") for sd in state_dicts]).transpose(1, 2).contiguous()
         self.b_act = torch.stack([t(sd, "act.action_out.linear.bias") for sd in state_dicts])
 
-    def log_probs(self, obs: torch.Tensor, policy_index: torch.Tensor) -> torch.Tensor:
-        G, B = obs.shape[0], obs.shape[1]
+    def select(self, policy_index: torch.Tensor):
+        """Per-segment weight stacks for a fixed segment->policy map, gathered once (the map changes only when a
+        new convention starts training) instead of once per env step."""
         idx = policy_index.to(self.device)
-        x = obs.to(self.dtype)                                                            # int8 -> float once
-        # [G, B, W-2, H-2, C, 3, 3] windows -> [G, B*P, C*9]
-        x = x.unfold(2, 3, 1).unfold(3, 3, 1).reshape(G, B * self.P, self.C * 9)
-        x = torch.relu(torch.baddbmm(self.b_conv[idx].unsqueeze(1), x, self.w_conv[idx]))         # [G, B*P, O]
-        x = x.reshape(G, B, self.P * self.O)
-        x = torch.relu(torch.baddbmm(self.b_fc1[idx].unsqueeze(1), x, self.w_fc1[idx]))
-        x = torch.relu(torch.baddbmm(self.b_fc2[idx].unsqueeze(1), x, self.w_fc2[idx]))
-        logits = torch.baddbmm(self.b_act[idx].unsqueeze(1), x, self.w_act[idx])
+        return tuple(w[idx].contiguous() for w in (self.w_conv, self.w_fc1, self.w_fc2, self.w_act)) + \
+            tuple(b[idx].unsqueeze(1).contiguous() for b in (self.b_conv, self.b_fc1, self.b_fc2, self.b_act))
+
+    def log_probs(self, obs: torch.Tensor, policy_index=None, selected=None) -> torch.Tensor:
+        G, B = obs.shape[0], obs.shape[1]
+        wc, w1, w2, wa, bc, b1, b2, ba = selected if selected is not None else self.select(policy_index)
+        x = obs.reshape(G, B, self.W * self.H * self.C).to(self.dtype)                    # int8 -> float once
+        x = torch.relu(torch.baddbmm(bc, x, wc))                                           # [G, B, P*O]
+        x = torch.relu(torch.baddbmm(b1, x, w1))
+        x = torch.relu(torch.baddbmm(b2, x, w2))
+        logits = torch.baddbmm(ba, x, wa)
         return torch.log_softmax(logits, dim=-1)                                           # Categorical(logits=).logits
 
-    def act(self, obs, policy_index, deterministic=False, generator=None):
+    def act(self, obs, policy_index=None, deterministic=False, generator=None, selected=None):
         """-> actions int64 [G, B, 1], their log-probs [G, B, 1] (reference FixedCategorical.sample / .mode)."""
-        logp = self.log_probs(obs, policy_index)
+        logp = self.log_probs(obs, policy_index, selected)
         if deterministic:
             a = logp.argmax(dim=-1, keepdim=True)
         else:

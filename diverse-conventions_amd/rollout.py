@@ -24,6 +24,7 @@ class PairedRollout:
         self.idx = [None, None]
         self.idx[ego_id] = torch.tensor(segment_policy_indices(self.segments, "ego"), device=dev)
         self.idx[1 - ego_id] = torch.tensor(segment_policy_indices(self.segments, "partner"), device=dev)
+        self.selected = [actors.select(i) for i in self.idx]     # gathered once per pairing
         self.deterministic = deterministic
         self.actions = torch.zeros((2, engine.num_kitchens), dtype=torch.int64, device=dev)
         self.logp = torch.zeros((2, engine.num_kitchens), dtype=actors.dtype, device=dev)
@@ -34,7 +35,7 @@ class PairedRollout:
         g = len(self.segments)
         for p in range(2):                                   # both sides, every segment, four GEMMs each
             obs = e.obs[p].view(g, self.threads, e.width, e.height, e.obs.shape[-1])
-            a, lp = self.actors.act(obs, self.idx[p], self.deterministic)
+            a, lp = self.actors.act(obs, deterministic=self.deterministic, selected=self.selected[p])
             self.actions[p].copy_(a.view(-1))
             self.logp[p].copy_(lp.view(-1))
         e.step(self.actions)                                 # int64 actions are read as they are
