@@ -9,12 +9,12 @@ from .overcooked_env import OvercookedMadrona
 from .env_utils import generate_env
 from .trajectory import TrajectoryBuffer
 from .rollout_ops import gae_returns
-from .policy import StackedActors
+from .policy import StackedActors, StackedCritics
 from .rollout import PairedRollout
 from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments, pairing_segments
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "OvercookedMadrona",
-    "generate_env", "TrajectoryBuffer", "gae_returns", "StackedActors", "PairedRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
+    "generate_env", "TrajectoryBuffer", "gae_returns", "StackedActors", "StackedCritics", "PairedRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
 ]

@@ -20,6 +20,8 @@ class StackedActors:
     obs int8/float [G, B, W, H, C] (G segments of B kitchens), policy_index [G] (which actor plays segment g)
     -> normalised action log-probabilities [G, B, A]."""
 
+    HEAD = "act.action_out.linear"          # final Linear of the network (reference utils/distributions.py:60-80)
+
     def __init__(self, state_dicts: Sequence[dict], obs_shape, device, dtype=torch.float32):
         self.W, self.H, self.C = (int(x) for x in obs_shape)
         self.device, self.dtype = torch.device(device), dtype
@@ -48,8 +50,8 @@ class StackedActors:
         self.b_fc1 = torch.stack([t(sd, "base.cnn.cnn.3.bias") for sd in state_dicts])
         self.w_fc2 = torch.stack([t(sd, "base.cnn.cnn.5.weight") for sd in state_dicts]).transpose(1, 2).contiguous()
         self.b_fc2 = torch.stack([t(sd, "base.cnn.cnn.5.bias") for sd in state_dicts])
-        self.w_act = torch.stack([t(sd, "act.action_out.linear.weight") for sd in state_dicts]).transpose(1, 2).contiguous()
-        self.b_act = torch.stack([t(sd, "act.action_out.linear.bias") for sd in state_dicts])
+        self.w_act = torch.stack([t(sd, self.HEAD + ".weight") for sd in state_dicts]).transpose(1, 2).contiguous()
+        self.b_act = torch.stack([t(sd, self.HEAD + ".bias") for sd in state_dicts])
 
     def select(self, policy_index: torch.Tensor):
         """Per-segment weight stacks for a fixed segment->policy map, gathered once (the map changes only when a
@@ -58,15 +60,18 @@ class StackedActors:
         return tuple(w[idx].contiguous() for w in (self.w_conv, self.w_fc1, self.w_fc2, self.w_act)) + \
             tuple(b[idx].unsqueeze(1).contiguous() for b in (self.b_conv, self.b_fc1, self.b_fc2, self.b_act))
 
-    def log_probs(self, obs: torch.Tensor, policy_index=None, selected=None) -> torch.Tensor:
+    def head_outputs(self, obs: torch.Tensor, policy_index=None, selected=None) -> torch.Tensor:
+        """Raw outputs of the final Linear: action logits for actors, values for critics.  [G, B, out]"""
         G, B = obs.shape[0], obs.shape[1]
         wc, w1, w2, wa, bc, b1, b2, ba = selected if selected is not None else self.select(policy_index)
         x = obs.reshape(G, B, self.W * self.H * self.C).to(self.dtype)                    # int8 -> float once
         x = torch.relu(torch.baddbmm(bc, x, wc))                                           # [G, B, P*O]
         x = torch.relu(torch.baddbmm(b1, x, w1))
         x = torch.relu(torch.baddbmm(b2, x, w2))
-        logits = torch.baddbmm(ba, x, wa)
-        return torch.log_softmax(logits, dim=-1)                                           # Categorical(logits=).logits
+        return torch.baddbmm(ba, x, wa)
+
+    def log_probs(self, obs: torch.Tensor, policy_index=None, selected=None) -> torch.Tensor:
+        return torch.log_softmax(self.head_outputs(obs, policy_index, selected), dim=-1)     # Categorical(logits=).logits
 
     def act(self, obs, policy_index=None, deterministic=False, generator=None, selected=None):
         """-> actions int64 [G, B, 1], their log-probs [G, B, 1] (reference FixedCategorical.sample / .mode)."""
@@ -78,6 +83,17 @@ class StackedActors:
             u = torch.rand(logp.shape, device=logp.device, dtype=logp.dtype, generator=generator).clamp_(1e-12, 1.0)
             a = (logp - torch.log(-torch.log(u))).argmax(dim=-1, keepdim=True)
         return a, logp.gather(-1, a)
+
+
+class StackedCritics(StackedActors):
+    """K reference-format critics (R_Critic = CNNBase + `v_out` Linear, train/MAPPO/r_actor_critic.py:139-199;
+    the sp / xp0[i] / xp1[i] / mp critics of MCPolicy, train/XD/MCPolicy.py:7-54), evaluated per segment in the
+    same four batched GEMMs.  `values(obs, critic_index)` -> [G, B, 1]."""
+
+    HEAD = "v_out"
+
+    def values(self, obs, critic_index=None, selected=None):
+        return self.head_outputs(obs, critic_index, selected)
 
 
 def segment_policy_indices(segments, side: str) -> List[int]:

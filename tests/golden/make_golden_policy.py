@@ -13,7 +13,7 @@ import torch
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, "/root/reference/train")
-from MAPPO.r_actor_critic import R_Actor      # noqa: E402
+from MAPPO.r_actor_critic import R_Actor, R_Critic      # noqa: E402
 
 
 class Space:
@@ -28,7 +28,7 @@ class Discrete(Space):
 if __name__ == "__main__":
     args = types.SimpleNamespace(hidden_size=64, gain=0.01, use_orthogonal=True, use_policy_active_masks=True,
                                  use_naive_recurrent_policy=False, use_recurrent_policy=False, recurrent_N=1,
-                                 use_ReLU=True, use_feature_normalization=True, stacked_frames=1, layer_N=2)
+                                 use_ReLU=True, use_feature_normalization=True, stacked_frames=1, layer_N=2, use_popart=False)
     obs = np.load(os.path.join(HERE, "guided_simple.npz"))["obs"]          # [T, P, W, H, C] int8
     obs = obs[::3].reshape(-1, 5, 4, 20)[:240]
     out = {"obs": obs}
@@ -47,6 +47,16 @@ if __name__ == "__main__":
         out[f"a{k}.logits"] = logits.numpy()
         out[f"a{k}.det_action"] = act.numpy()
         out[f"a{k}.det_logp"] = logp.numpy()
+    for k in range(2):                                    # critics: same trunk, scalar value head (r_actor_critic.py:139-199)
+        torch.manual_seed(200 + k)
+        critic = R_Critic(args, Space((5, 4, 20)))
+        with torch.no_grad():
+            for p in critic.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+            values, _ = critic(torch.from_numpy(obs).float(), torch.zeros(len(obs), 1, 64), torch.ones(len(obs), 1))
+        for name, t in critic.state_dict().items():
+            out[f"c{k}.{name}"] = t.numpy()
+        out[f"c{k}.values"] = values.numpy()
     np.savez_compressed(os.path.join(HERE, "policy_cases.npz"), **out)
     print("wrote policy_cases.npz", os.path.getsize(os.path.join(HERE, "policy_cases.npz")) // 1024, "KiB",
           [k for k in out if k.startswith("a0.")])

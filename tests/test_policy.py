@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+from diverse_conventions_amd.policy import StackedActors, StackedCritics, segment_policy_indices
 from diverse_conventions_amd.sharding import pairing_segments
 
 TOL = 2e-5
@@ -40,6 +40,18 @@ def check(device):
     s, _ = actors.act(big, torch.tensor([0]))
     freq = torch.bincount(s.flatten().cpu(), minlength=6).float() / 20000
     assert (freq - logp[0, 0].exp().cpu()).abs().max() < 0.02
+
+
+def test_stacked_critics_match_reference_cpu():
+    z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
+    sds = [{k[len(f"c{i}."):]: z[k] for k in z.files if k.startswith(f"c{i}.") and not k.endswith(".values")} for i in range(2)]
+    critics = StackedCritics(sds, (5, 4, 20), "cpu")
+    seg = torch.from_numpy(z["obs"]).reshape(4, 60, 5, 4, 20)
+    order = [1, 0, 0, 1]
+    v = critics.values(seg, torch.tensor(order))
+    assert v.shape == (4, 60, 1)
+    for g, k in enumerate(order):
+        assert np.abs(v[g].numpy() - z[f"c{k}.values"][g * 60:(g + 1) * 60]).max() < TOL
 
 
 def test_stacked_actors_match_reference_cpu():
