@@ -376,3 +376,30 @@ def test_no_stray_writes_around_any_output(layout_params):
         assert bool((raw[:pad] == fill).all()) and bool((raw[-pad:] == fill).all())
     assert int((obs == 0x55).sum()) == 0               # and every byte inside was written (values are 0..20)
     eng.close()
+
+
+def test_full_size_soak_every_kitchen(layout_params):
+    """65 536 kitchens x 2000 steps with per-kitchen perturbed guided streams (cooking, deliveries, ten horizon
+    resets): rewards and dones of EVERY kitchen compared every step, the full observation tensor every 97 steps,
+    the full state at the end -- no sampling."""
+    params = layout_params["simple"]
+    n, T = 65536, 2000
+    g = load_golden(os.path.join(GOLDEN, "guided_simple.npz"))["actions"]          # 600 steps, resets in sync
+    rng = np.random.default_rng(123)
+    ora = oracle.OracleVecEnv(params, n, nthreads=16)
+    eng = _engine(params, n)
+    total = 0
+    for t in range(T):
+        base = np.broadcast_to(g[t % 600][:, None], (2, n))
+        acts = np.where(rng.random((1, n)) < 0.9, base, rng.integers(0, 6, size=(2, n))).astype(np.int32)
+        obs, rew, done = eng.step(torch.from_numpy(acts).cuda())
+        want_obs = t % 97 == 0 or t == T - 1
+        oobs, orew, odone = ora.step(acts, want_obs=want_obs)
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone), t
+        if want_obs:
+            assert np.array_equal(obs.cpu().numpy(), oobs), t
+        total += int(orew[0].sum())
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    assert total > 10 * n                       # the streams keep cooking and delivering at this scale too
+    eng.close()
