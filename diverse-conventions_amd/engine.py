@@ -264,6 +264,23 @@ class OvercookedEngine:
         count = records.numel() * records.element_size() // self.record_bytes
         native.check(self._L.oc_import_states(self._handle, first, count, _ptr(records), self._stream()))
 
+    def state_dict(self):
+        """Checkpoint of the simulation (the reference never checkpoints env state; torch
+        format like its model checkpoints): native records on the CPU plus what is needed to validate a reload."""
+        return {"records": self.export_states().cpu(), "layout": {k: (list(v) if isinstance(v, (list, tuple)) else v)
+                                                                   for k, v in self.params.items()},
+                "num_kitchens": self.num_kitchens, "record_bytes": self.record_bytes}
+
+    def load_state_dict(self, sd):
+        if sd["num_kitchens"] != self.num_kitchens or sd["record_bytes"] != self.record_bytes:
+            raise ValueError("checkpoint was taken from an engine of another size")
+        if any(sd["layout"][k] != (list(v) if isinstance(v, (list, tuple)) else v) for k, v in self.params.items()):
+            raise ValueError("checkpoint was taken from another layout")
+        rec = sd["records"].contiguous()
+        tiles, players, ts = unpack_states(rec.numpy().view(np.uint32), self.size)
+        self.set_state(tiles, players, ts)              # host path: validates player positions before upload
+        self.observe()
+
     def get_state(self, first=0, count=None):
         """-> (tiles int8 [n,S,4], players int8 [n,2,6], timestep int32 [n]); synchronises."""
         count = self.num_kitchens - first if count is None else count

@@ -403,3 +403,25 @@ def test_full_size_soak_every_kitchen(layout_params):
         assert np.array_equal(x, y)
     assert total > 10 * n                       # the streams keep cooking and delivering at this scale too
     eng.close()
+
+
+def test_env_checkpoint_roundtrip(layout_params, tmp_path):
+    """state_dict -> torch.save -> torch.load -> load_state_dict into a fresh engine: the rollout continues
+    exactly where it stopped."""
+    params = layout_params["random3"]
+    n = 333
+    acts = torch.from_numpy(_mixed_actions("random3", 120, n, seed=8)).cuda()
+    a = _engine(params, n)
+    a.rollout(acts, 77)
+    torch.save(a.state_dict(), tmp_path / "env.pt")
+    b = _engine(params, n)
+    b.load_state_dict(torch.load(tmp_path / "env.pt", weights_only=False))
+    assert torch.equal(a.observe(), b.obs)
+    for t in range(77, 120):
+        a.step(acts[t]); b.step(acts[t])
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+    other = _engine(layout_params["simple"], n)
+    with pytest.raises(ValueError):
+        other.load_state_dict(a.state_dict())
+    for e in (a, b, other):
+        e.close()
