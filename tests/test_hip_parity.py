@@ -425,3 +425,22 @@ def test_env_checkpoint_roundtrip(layout_params, tmp_path):
         other.load_state_dict(a.state_dict())
     for e in (a, b, other):
         e.close()
+
+
+def test_create_destroy_does_not_leak(layout_params):
+    """50 engines of 100k kitchens created, stepped and closed: device memory returns to where it was."""
+    params = layout_params["unident_s"]
+    torch.cuda.synchronize()
+    warm = _engine(params, 100_000); warm.close()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(50):
+        eng = _engine(params, 100_000)
+        eng.step(torch.zeros((2, 100_000), dtype=torch.int32, device="cuda"))
+        if i % 10 == 0:
+            eng.set_tuning(8 + 4 * (i // 10), 2, 8)      # re-specialises: the old code object must be unloaded
+        eng.close()
+        del eng
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 2**20, (free0, free1)
