@@ -44,3 +44,15 @@ for i in range(len(names) - 1):
 xcc = buf[:, 10]
 print("  waves per XCC id:", np.bincount(xcc.astype(np.int64) & 0xF))
 eng.close()
+
+# where do the slow waves live?  end time by XCD and by dispatch order
+end = t[:, -1] - t0
+for x in range(8):
+    sel = (xcc.astype(np.int64) & 0xF) == x
+    print(f"  XCC {x}: start median {np.median(t[sel, 0] - t0):5.2f}  end median {np.median(end[sel]):5.2f}  max {end[sel].max():5.2f}")
+q = np.array_split(np.arange(nw), 8)
+print("  end median by wave-id octile:", [round(float(np.median(end[i])), 2) for i in q])
+print("  start median by wave-id octile:", [round(float(np.median((t[:, 0] - t0)[i])), 2) for i in q])
+half = nw // 2
+for nm, sel in (("first-dispatched half ", slice(0, half)), ("second-dispatched half", slice(half, nw))):
+    print(f"  {nm}: " + "  ".join(f"{names[i]} {np.median(t[sel, i] - t0):.2f}" for i in range(len(names))))
