@@ -36,36 +36,67 @@ __device__ __forceinline__ float denorm(const GaeArgs &a, float v) {
     return a.denormalize ? __fadd_rn(__fmul_rn(v, a.vn_std), a.vn_mean) : v;      // valuenorm.py:81-83
 }
 
-// One thread per (env, agent) column, coalesced across columns at every step.  Measured variants at
-// T=200, M=131072 (524 MB): this form 0.153 ms; an 8-step register prefetch ring 0.159 ms; four columns per
-// thread with 16-byte accesses 0.166 ms -- the scan is bound by five concurrent 512 KB-strided streams,
-// not by load latency or access width, so the simplest form stays.
+// One thread per (env, agent) column, coalesced across columns at every step.  The scan is serial in t, and
+// loads and stores retire through one in-order counter (vmcnt), so a load waited for behind younger stores waits
+// for those stores too.  The loop therefore runs in rounds of kRound steps with the NEXT round's inputs issued
+// before the current round's results are stored: the wait for them is a counted vmcnt(#stores) that the
+// compiler can emit because each round is straight-line code.
+constexpr int kRound = 4;
+
+struct GaeIn { float r, m, v, b; };
+
+__device__ __forceinline__ GaeIn gae_load(const GaeArgs &a, long long t, long long m) {
+    GaeIn x;
+    x.r = a.rewards[t * a.M + m];
+    x.m = a.masks[(t + 1) * a.M + m];
+    x.v = a.values[t * a.M + m];
+    x.b = a.proper_time_limits ? a.bad_masks[(t + 1) * a.M + m] : 1.0f;
+    return x;
+}
+
+__device__ __forceinline__ void gae_step(const GaeArgs &a, const GaeIn &x, long long t, long long m, float &gae, float &v_next) {
+    const float v = denorm(a, x.v);
+    // delta = r + gamma * v[t+1] * mask[t+1] - v[t]                          (shared_buffer.py:262-264, 291-293)
+    const float delta = __fsub_rn(__fadd_rn(x.r, __fmul_rn(__fmul_rn(a.gamma, v_next), x.m)), v);
+    if (a.proper_time_limits) {
+        // gae = delta + gamma*lambda * gae * mask ; gae *= bad_mask            (shared_buffer.py:265-266)
+        // (the un-normalised branch orders it gamma*lambda * mask * gae, :272 -- both orders are kept)
+        const float prod = a.denormalize ? __fmul_rn(__fmul_rn(a.gamma_lambda, gae), x.m)
+                                         : __fmul_rn(__fmul_rn(a.gamma_lambda, x.m), gae);
+        gae = __fmul_rn(__fadd_rn(delta, prod), x.b);
+    } else {
+        // gae = delta + gamma*lambda * mask * gae                              (shared_buffer.py:294, 299)
+        gae = __fadd_rn(delta, __fmul_rn(__fmul_rn(a.gamma_lambda, x.m), gae));
+    }
+    const float ret = __fadd_rn(gae, v);
+    a.returns[t * a.M + m] = ret;
+    if (a.advantages) a.advantages[t * a.M + m] = __fsub_rn(ret, v);             // r_mappo.py:175-177
+    v_next = v;
+}
+
 __global__ __launch_bounds__(256) void oc_gae_kernel(const GaeArgs a) {
     const long long m = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (m >= a.M) return;
     float gae = 0.0f;
     float v_next = denorm(a, a.values[a.T * a.M + m]);
-    for (long long t = a.T - 1; t >= 0; --t) {
-        const float r = a.rewards[t * a.M + m];
-        const float mask = a.masks[(t + 1) * a.M + m];
-        const float v = denorm(a, a.values[t * a.M + m]);
-        // delta = r + gamma * v[t+1] * mask[t+1] - v[t]                      (shared_buffer.py:262-264, 291-293)
-        const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(__fmul_rn(a.gamma, v_next), mask)), v);
-        if (a.proper_time_limits) {
-            // gae = delta + gamma*lambda * gae * mask ; gae *= bad_mask        (shared_buffer.py:265-266)
-            // (the un-normalised branch orders it gamma*lambda * mask * gae, :272 -- both orders are kept)
-            const float prod = a.denormalize ? __fmul_rn(__fmul_rn(a.gamma_lambda, gae), mask)
-                                             : __fmul_rn(__fmul_rn(a.gamma_lambda, mask), gae);
-            gae = __fmul_rn(__fadd_rn(delta, prod), a.bad_masks[(t + 1) * a.M + m]);
-        } else {
-            // gae = delta + gamma*lambda * mask * gae                          (shared_buffer.py:294, 299)
-            gae = __fadd_rn(delta, __fmul_rn(__fmul_rn(a.gamma_lambda, mask), gae));
+    long long t = a.T - 1;
+    if (t >= kRound - 1) {
+        GaeIn cur[kRound], nxt[kRound];
+#pragma unroll
+        for (int i = 0; i < kRound; ++i) cur[i] = gae_load(a, t - i, m);
+        for (; t >= 2 * kRound - 1; t -= kRound) {
+#pragma unroll
+            for (int i = 0; i < kRound; ++i) nxt[i] = gae_load(a, t - kRound - i, m);      // next round, in flight
+#pragma unroll
+            for (int i = 0; i < kRound; ++i) gae_step(a, cur[i], t - i, m, gae, v_next);
+#pragma unroll
+            for (int i = 0; i < kRound; ++i) cur[i] = nxt[i];
         }
-        const float ret = __fadd_rn(gae, v);
-        a.returns[t * a.M + m] = ret;
-        if (a.advantages) a.advantages[t * a.M + m] = __fsub_rn(ret, v);         // r_mappo.py:175-177
-        v_next = v;
+#pragma unroll
+        for (int i = 0; i < kRound; ++i) gae_step(a, cur[i], t - i, m, gae, v_next);        // last full round
+        t -= kRound;
     }
+    for (; t >= 0; --t) gae_step(a, gae_load(a, t, m), t, m, gae, v_next);                  // remainder (< kRound steps)
 }
 
 }  // namespace
