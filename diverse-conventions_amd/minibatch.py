@@ -1,0 +1,114 @@
+"""PPO minibatch generators on the device.
+
+The reference's `SharedReplayBuffer.feed_forward_generator` / `partial_ff_generator`
+(train/MAPPO/utils/shared_buffer.py:306-366, 368-429) draw `torch.randperm` on the host, flatten every buffer to
+`[T*N*A, ...]` and fancy-index ten tensors per minibatch -- the float32 observations twice (`share_obs`, `obs`).
+Here the permutation is drawn on the device, the int8 observation rows are gathered straight out of the
+trajectory the step kernel wrote (`TrajectoryBuffer.obs`, `[T+1, P, N, W, H, C]`) with the cast to the
+consumer's dtype fused, and all scalar columns go in one launch.  For the same permutation the minibatches are
+element-for-element the reference's (tests/golden/minibatch_cases.npz).
+"""
+import torch
+
+from .rollout_ops import gather_columns, gather_rows
+
+_SCALARS = ("actions", "value_preds", "returns", "masks", "active_masks", "action_log_probs")
+
+
+class MinibatchSource:
+    """Holds what an update reads.
+
+    obs             int8 [T+1, P, N, W, H, C]  (engine layout: agent-major, as TrajectoryBuffer stores it)
+    actions, action_log_probs  [T, N, A, 1];  value_preds, returns, masks, active_masks  [T+1, N, A, 1]
+    rnn_states, rnn_states_critic  [T+1, N, A, recurrent_N, hidden] (optional);  available_actions [T+1, N, A, n] (optional;
+    Overcooked's are all ones -- sim.cpp:771 -- and a broadcast view is yielded when absent)
+    all float32 in the reference's layout, on the device of `obs`.
+    """
+
+    def __init__(self, obs, actions, value_preds, returns, masks, active_masks, action_log_probs, rnn_states=None,
+                 rnn_states_critic=None, available_actions=None, num_actions=6):
+        if obs.dtype != torch.int8 or obs.dim() != 6 or not obs.is_contiguous():
+            raise ValueError("obs must be a contiguous int8 [T+1, P, N, W, H, C] tensor")
+        self.obs = obs
+        self.T, self.A, self.N = obs.shape[0] - 1, obs.shape[1], obs.shape[2]
+        self.cols = dict(actions=actions, value_preds=value_preds, returns=returns, masks=masks, active_masks=active_masks,
+                         action_log_probs=action_log_probs, rnn_states=rnn_states, rnn_states_critic=rnn_states_critic,
+                         available_actions=available_actions)
+        for k, t in self.cols.items():
+            if t is None:
+                continue
+            want_t = self.T if k in ("actions", "action_log_probs") else self.T + 1
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[:3]) != (want_t, self.N, self.A):
+                raise ValueError(f"{k} must be contiguous float32 [{want_t}, {self.N}, {self.A}, ...]")
+        self.num_actions = num_actions
+
+    @classmethod
+    def from_trajectory(cls, traj, value_preds, returns, masks, action_log_probs, active_masks=None, **kw):
+        """`traj`: a filled TrajectoryBuffer; its int32 `[T, P, N]` actions become the reference's float `[T, N, A, 1]`."""
+        actions = traj.actions.permute(0, 2, 1).unsqueeze(-1).float().contiguous()
+        if active_masks is None:
+            active_masks = torch.ones_like(masks)
+        return cls(traj.obs, actions, value_preds, returns, masks, active_masks, action_log_probs, **kw)
+
+    def permutation(self, batch_size, generator=None):
+        return torch.randperm(batch_size, device=self.obs.device, generator=generator)
+
+    def _sampler(self, batch_size, num_mini_batch, mini_batch_size, perm, generator):
+        if num_mini_batch is None:
+            raise ValueError("num_mini_batch is required")
+        if mini_batch_size is None:
+            if batch_size < num_mini_batch:                                       # shared_buffer.py:316-324
+                raise AssertionError(f"PPO requires the batch ({batch_size}) to be at least the number of minibatches ({num_mini_batch})")
+            mini_batch_size = batch_size // num_mini_batch
+        if perm is None:
+            perm = self.permutation(batch_size, generator)
+        else:
+            perm = torch.as_tensor(perm, dtype=torch.int64, device=self.obs.device).contiguous()
+            if perm.numel() and (int(perm.min()) < 0 or int(perm.max()) >= batch_size):
+                raise IndexError("permutation entries must lie in [0, batch_size)")
+        return [perm[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(num_mini_batch)]   # :326-327
+
+    def _batch(self, idx, obs_rows, advantages, row_mul, row_add, obs_dtype, norm_stats):
+        obs_batch = gather_rows(self.obs.view(-1, *self.obs.shape[3:]), obs_rows, dtype=obs_dtype)
+        names = [k for k in _SCALARS + ("rnn_states", "rnn_states_critic", "available_actions") if self.cols[k] is not None]
+        tensors = [self.cols[k].view(-1, *self.cols[k].shape[3:]) for k in names]
+        stats = None
+        if advantages is not None:
+            names.append("adv_targ")
+            tensors.append(advantages.view(-1, *advantages.shape[3:]))
+            if norm_stats is not None:
+                stats = {len(tensors) - 1: norm_stats}
+        out = {}
+        for lo in range(0, len(names), 8):
+            part = gather_columns(tensors[lo:lo + 8], idx, row_mul, row_add,
+                                  {k - lo: v for k, v in (stats or {}).items() if lo <= k < lo + 8})
+            out.update(zip(names[lo:lo + 8], part))
+        avail = out.get("available_actions")
+        if avail is None:
+            avail = torch.ones((1, self.num_actions), dtype=torch.float32, device=self.obs.device).expand(idx.numel(), -1)
+        return (obs_batch, obs_batch, out.get("rnn_states"), out.get("rnn_states_critic"), out["actions"], out["value_preds"],
+                out["returns"], out["masks"], out["active_masks"], out["action_log_probs"], out.get("adv_targ"), avail)
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, perm=None, generator=None,
+                               obs_dtype=torch.float32, norm_stats=None):
+        """Yields the reference's 12-tuple (share_obs, obs, rnn_states, rnn_states_critic, actions, value_preds, returns,
+        masks, active_masks, old_action_log_probs, adv_targ, available_actions); share_obs IS obs (Overcooked's state is
+        its observation, overcooked2_env.py:97-98).  Flat row r = (t*N + n)*A + a (shared_buffer.py:331-343).
+        advantages [T, N, A, 1] f32 or None; with `norm_stats` (from normalize_advantages(..., out=None) statistics) raw
+        advantages are normalised while they are gathered.  obs_dtype torch.float32 (reference) or torch.int8."""
+        T, N, A = self.T, self.N, self.A
+        for idx in self._sampler(T * N * A, num_mini_batch, mini_batch_size, perm, generator):
+            a = idx % A
+            tn = idx // A
+            obs_rows = ((tn // N) * A + a) * N + tn % N                           # (t, a, n) in the agent-major trajectory
+            yield self._batch(idx.contiguous(), obs_rows, advantages, 1, 0, obs_dtype, norm_stats)
+
+    def partial_ff_generator(self, advantages, agent, num_mini_batch=None, mini_batch_size=None, perm=None, generator=None,
+                             obs_dtype=torch.float32, norm_stats=None):
+        """One agent's samples only (shared_buffer.py:368-429): flat row r = t*N + n."""
+        T, N, A = self.T, self.N, self.A
+        if not 0 <= agent < A:
+            raise IndexError("agent index out of range")
+        for idx in self._sampler(T * N, num_mini_batch, mini_batch_size, perm, generator):
+            obs_rows = ((idx // N) * A + agent) * N + idx % N
+            yield self._batch(idx.contiguous(), obs_rows, advantages, A, agent, obs_dtype, norm_stats)

@@ -42,3 +42,109 @@ def gae_returns(rewards, value_preds, masks, bad_masks=None, gamma=0.99, gae_lam
                                              float(gamma), float(gae_lambda), denorm, mean, std,
                                              1 if use_proper_time_limits else 0, stream))
     return returns, adv
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32_cuda(name, t):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
+
+
+_workspaces = {}
+
+
+def normalize_advantages(advantages, active_masks=None, std_over="reference", out=None):
+    """`(adv - nanmean) / (std + 1e-5)` of the reference's `calc_advantanges` / `R_MAPPO.train`
+    (train/XD/xd.py:240-244, train/MAPPO/r_mappo.py:177-181) in three launches, no host synchronisation.
+
+    advantages [T, N, A, 1] f32 (e.g. from `gae_returns`); active_masks = `buffer.active_masks[:-1]` or None (all active).
+    std_over="reference": the reference selects the entries for the std with `copy != nan`, which keeps the NaN-masked
+    inactive ones, so std and advantages are NaN whenever an entry is inactive; "active": std of the active entries.
+    -> (normalised advantages (`out`, may be `advantages` itself), stats f32[2] = {mean, std} on the device)
+    """
+    if std_over not in ("reference", "active"):
+        raise ValueError("std_over must be 'reference' or 'active'")
+    _f32_cuda("advantages", advantages)
+    if active_masks is not None:
+        active_masks = active_masks.contiguous()
+        _f32_cuda("active_masks", active_masks)
+        if active_masks.numel() != advantages.numel():
+            raise ValueError("active_masks must have the shape of advantages (pass buffer.active_masks[:-1])")
+    if out is None:
+        out = torch.empty_like(advantages)
+    _f32_cuda("out", out)
+    L = native.lib()
+    ws = _workspaces.get(advantages.device)
+    if ws is None:
+        ws = _workspaces[advantages.device] = torch.empty(L.oc_advantage_workspace_bytes(), dtype=torch.uint8, device=advantages.device)
+    stats = torch.empty(2, dtype=torch.float32, device=advantages.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    native.check(L.oc_advantage_normalize(p(advantages), p(active_masks), advantages.numel(), 1 if std_over == "active" else 0,
+                                          p(out), p(stats), p(ws), _stream(advantages)))
+    return out, stats
+
+
+def gather_rows(src, index, out=None, dtype=None):
+    """out[i] = src[index[i]] for byte rows: src int8 [R, ...] (contiguous, trailing sizes multiply to a multiple of 4),
+    index int64 [n] on the device (None = all rows in order); dtype torch.int8 (default) or torch.float32 (cast fused).
+    Indices outside [0, R) are clamped, not faulted on."""
+    if src.dtype != torch.int8 or not src.is_cuda or not src.is_contiguous():
+        raise ValueError("src must be a contiguous int8 CUDA tensor")
+    dtype = dtype or torch.int8
+    if dtype not in (torch.int8, torch.float32):
+        raise ValueError("dtype must be torch.int8 or torch.float32")
+    R = src.shape[0]
+    row_bytes = src[0].numel() if R else 0
+    if index is not None and (index.dtype != torch.int64 or not index.is_cuda or not index.is_contiguous() or index.dim() != 1):
+        raise ValueError("index must be a contiguous 1-d int64 CUDA tensor")
+    n = R if index is None else index.numel()
+    if out is None:
+        out = torch.empty((n, *src.shape[1:]), dtype=dtype, device=src.device)
+    elif out.dtype != dtype or not out.is_contiguous() or out.numel() != n * row_bytes or out.device != src.device:
+        raise ValueError("out must be a contiguous tensor of n rows in the requested dtype on src's device")
+    if n == 0:
+        return out
+    native.check(native.lib().oc_gather_rows(ctypes.c_void_p(src.data_ptr()), R, row_bytes,
+                                             ctypes.c_void_p(index.data_ptr()) if index is not None else None, n,
+                                             ctypes.c_void_p(out.data_ptr()), 1 if dtype == torch.float32 else 0, _stream(src)))
+    return out
+
+
+def gather_columns(columns, index, row_mul=1, row_add=0, norm_stats=None, outs=None):
+    """Gather up to 8 four-byte-element columns in one launch: outs[c][i] = columns[c][index[i] * row_mul + row_add].
+    columns: contiguous CUDA tensors [R_c, ...] of a 4-byte dtype; norm_stats: {column position: stats f32[2]} applies
+    `(x - mean) / (std + 1e-5)` on the fly (stats from `normalize_advantages`)."""
+    n_cols = len(columns)
+    if not 1 <= n_cols <= 8:
+        raise ValueError("1..8 columns per call")
+    if index.dtype != torch.int64 or not index.is_cuda or not index.is_contiguous() or index.dim() != 1:
+        raise ValueError("index must be a contiguous 1-d int64 CUDA tensor")
+    n = index.numel()
+    vp = ctypes.c_void_p
+    src, dst, stats = (vp * n_cols)(), (vp * n_cols)(), (vp * n_cols)()
+    rows, words = (ctypes.c_int64 * n_cols)(), (ctypes.c_int32 * n_cols)()
+    results = []
+    for c, t in enumerate(columns):
+        if t.element_size() != 4 or not t.is_cuda or not t.is_contiguous() or t.dim() < 1:
+            raise ValueError("columns must be contiguous CUDA tensors of a 4-byte dtype")
+        w = t[0].numel() if t.shape[0] else 0
+        if w < 1:
+            raise ValueError("empty column")
+        o = outs[c] if outs is not None else torch.empty((n, *t.shape[1:]), dtype=t.dtype, device=t.device)
+        if o.dtype != t.dtype or not o.is_contiguous() or o.numel() != n * w:
+            raise ValueError("bad output tensor for column %d" % c)
+        src[c], dst[c], rows[c], words[c] = t.data_ptr(), o.data_ptr(), t.shape[0], w
+        s = (norm_stats or {}).get(c)
+        if s is not None:
+            _f32_cuda("norm_stats", s)
+            if t.dtype != torch.float32:
+                raise ValueError("only float32 columns can be normalised")
+        stats[c] = s.data_ptr() if s is not None else None
+        results.append(o)
+    if n:
+        native.check(native.lib().oc_gather_columns(n_cols, src, rows, words, dst, stats, vp(index.data_ptr()), n, int(row_mul),
+                                                    int(row_add), _stream(index)))
+    return results

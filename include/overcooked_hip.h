@@ -147,7 +147,7 @@ int oc_set_state(oc_engine *e, int64_t first, int64_t count, const void *host_sr
 int oc_export_states(oc_engine *e, int64_t first, int64_t count, void *d_dst, void *stream);
 int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_src, void *stream);
 
-/* ---- runner-side op ----------------------------------------------------------------
+/* ---- runner-side ops ---------------------------------------------------------------
  * Generalised advantage estimation over a whole trajectory batch in one launch; replaces the GAE branches
  * of SharedReplayBuffer.compute_returns (train/MAPPO/utils/shared_buffer.py:248-304) and the advantage
  * subtraction of train/MAPPO/r_mappo.py:174-177.  All tensors f32, time-major, M = envs * agents:
@@ -158,6 +158,33 @@ int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_s
 int oc_gae_returns(const float *d_rewards, const float *d_value_preds, const float *d_masks, const float *d_bad_masks,
                    float *d_returns, float *d_advantages, int64_t T, int64_t M, double gamma, double gae_lambda,
                    int denormalize, float vn_mean, float vn_std, int proper_time_limits, void *stream);
+
+/* Advantage normalisation of train/XD/xd.py:240-244 (= train/MAPPO/r_mappo.py:177-181) over n f32 elements:
+ *   mean = nanmean over entries with active_mask != 0 ; std = unbiased std ; out = (adv - mean) / (std + 1e-5).
+ * std_over_active = 0 keeps the reference's behaviour (its `copy != nan` selects every entry, so the std --
+ * and every output -- is NaN as soon as one entry is inactive); 1 takes the std of the active entries.
+ * d_active_masks may be NULL (all active); d_out may alias d_adv or be NULL (statistics only);
+ * d_stats receives {mean, std}; d_workspace holds oc_advantage_workspace_bytes() bytes.  Sums are taken in f64
+ * in a fixed order: reproducible run to run, within 1e-6 of torch's f32 reductions. */
+int64_t oc_advantage_workspace_bytes(void);
+int oc_advantage_normalize(const float *d_adv, const float *d_active_masks, int64_t n, int std_over_active, float *d_out,
+                           float *d_stats, void *d_workspace, void *stream);
+
+/* Row gather, dst row i <- src row d_index[i] (NULL index = identity): the data movement of
+ * SharedReplayBuffer.feed_forward_generator / partial_ff_generator (shared_buffer.py:331-345, 393-407) and of
+ * diaginsert / partinsert (:167-179, :200-212) with the index arithmetic done by the caller on the device.
+ * Rows are row_bytes bytes of int8 observations (multiple of 4, <= 5120); dst_dtype 0 copies the bytes,
+ * 1 writes f32 (the reference's buffer dtype; cast fused).  Indices outside [0, src_rows) are clamped. */
+int oc_gather_rows(const void *d_src, int64_t src_rows, int32_t row_bytes, const int64_t *d_index, int64_t n_rows, void *d_dst,
+                   int dst_dtype, void *stream);
+/* The scalar side of a minibatch: up to 8 columns of words[c] 4-byte words per row (value_preds, returns, masks,
+ * active_masks, actions, action_log_probs, advantages, rnn_states ...) gathered in one launch; source row =
+ * d_index[i] * row_mul + row_add -- (1, 0) for feed_forward_generator, (num_agents, agent) for
+ * partial_ff_generator.  d_src / d_dst / src_rows / words / d_norm_stats are HOST arrays of n_cols entries;
+ * a non-NULL d_norm_stats[c] (device {mean, std} from oc_advantage_normalize) normalises column c on the fly. */
+int oc_gather_columns(int32_t n_cols, const void *const *d_src, const int64_t *src_rows, const int32_t *words, void *const *d_dst,
+                      const float *const *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
+                      void *stream);
 
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);
