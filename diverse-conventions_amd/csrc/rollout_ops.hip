@@ -422,3 +422,106 @@ extern "C" int oc_gather_columns(int32_t n_cols, const void *const *d_src, const
     hipLaunchKernelGGL(oc_gather_columns_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
 }
+
+// ======================================================================================================
+// Sample records.  A minibatch reads seven one-word columns per sample (actions, value_preds, returns, masks,
+// active_masks, action_log_probs, advantages) at a random row: seven 32-byte sectors for 28 useful bytes.
+// oc_pack_columns interleaves up to eight columns into one 32-byte record per sample, once per update
+// (streaming, coalesced); oc_gather_records then reads ONE sector per sample and writes the columns out
+// separately and contiguously, as the reference's generators yield them.
+// ======================================================================================================
+namespace {
+
+struct PackArgs {
+    const uint32_t *src[8];
+    int n_cols;
+    long long n_rows;
+    u32x4 *packed;              // [n_rows][2]
+};
+
+__global__ __launch_bounds__(256) void oc_pack_columns_kernel(const PackArgs a) {
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n_rows; i += stride) {
+        uint32_t w[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] = c < a.n_cols ? a.src[c][i] : 0u;
+        u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
+        a.packed[2 * i] = lo;
+        a.packed[2 * i + 1] = hi;
+    }
+}
+
+struct RecordArgs {
+    const u32x4 *packed;
+    uint32_t *dst[8];
+    int n_cols, norm_col;       // norm_col < 0: none
+    const float *norm_stats;
+    const long long *index;
+    long long n_rows, src_rows, row_mul, row_add;
+};
+
+__global__ __launch_bounds__(256) void oc_gather_records_kernel(const RecordArgs a) {
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    float mean = 0.0f, denom = 1.0f;
+    if (a.norm_col >= 0) {
+        mean = a.norm_stats[0];
+        denom = __fadd_rn(a.norm_stats[1], 1e-5f);
+    }
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n_rows; i += stride) {
+        long long r = a.index[i] * a.row_mul + a.row_add;
+        r = r < 0 ? 0 : (r >= a.src_rows ? a.src_rows - 1 : r);
+        const u32x4 lo = a.packed[2 * r], hi = a.packed[2 * r + 1];
+        uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c >= a.n_cols) break;
+            uint32_t v = w[c];
+            if (c == a.norm_col) v = __float_as_uint(__fdiv_rn(__fsub_rn(__uint_as_float(v), mean), denom));
+            a.dst[c][i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int oc_pack_columns(int32_t n_cols, const void *const *d_src, int64_t n_rows, void *d_packed, void *stream) {
+    if (n_cols < 1 || n_cols > 8 || !d_src || !d_packed || n_rows < 0 || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return OC_ERR_INVALID_ARG;
+    if (n_rows == 0) return OC_OK;
+    PackArgs a = {};
+    for (int c = 0; c < n_cols; ++c) {
+        if (!d_src[c] || (reinterpret_cast<uintptr_t>(d_src[c]) & 3)) return OC_ERR_INVALID_ARG;
+        a.src[c] = static_cast<const uint32_t *>(d_src[c]);
+    }
+    a.n_cols = n_cols;
+    a.n_rows = n_rows;
+    a.packed = static_cast<u32x4 *>(d_packed);
+    const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_rows + 255) / 256));
+    hipLaunchKernelGGL(oc_pack_columns_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
+}
+
+extern "C" int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, void *const *d_dst, int32_t norm_col,
+                                 const float *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
+                                 void *stream) {
+    if (!d_packed || src_rows < 1 || n_cols < 1 || n_cols > 8 || !d_dst || !d_index || n_rows < 0 || row_mul < 1 || row_add < 0 ||
+        norm_col >= n_cols || (norm_col >= 0 && !d_norm_stats) || (reinterpret_cast<uintptr_t>(d_packed) & 15))
+        return OC_ERR_INVALID_ARG;
+    if (n_rows == 0) return OC_OK;
+    RecordArgs a = {};
+    a.packed = static_cast<const u32x4 *>(d_packed);
+    for (int c = 0; c < n_cols; ++c) {
+        if (!d_dst[c] || (reinterpret_cast<uintptr_t>(d_dst[c]) & 3)) return OC_ERR_INVALID_ARG;
+        a.dst[c] = static_cast<uint32_t *>(d_dst[c]);
+    }
+    a.n_cols = n_cols;
+    a.norm_col = norm_col < 0 ? -1 : norm_col;
+    a.norm_stats = d_norm_stats;
+    a.index = reinterpret_cast<const long long *>(d_index);
+    a.n_rows = n_rows;
+    a.src_rows = src_rows;
+    a.row_mul = row_mul;
+    a.row_add = row_add;
+    const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_rows + 255) / 256));
+    hipLaunchKernelGGL(oc_gather_records_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
+}

@@ -10,7 +10,7 @@ element-for-element the reference's (tests/golden/minibatch_cases.npz).
 """
 import torch
 
-from .rollout_ops import gather_columns, gather_rows
+from .rollout_ops import gather_columns, gather_records, gather_rows, pack_columns
 
 _SCALARS = ("actions", "value_preds", "returns", "masks", "active_masks", "action_log_probs")
 
@@ -41,6 +41,7 @@ class MinibatchSource:
             if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[:3]) != (want_t, self.N, self.A):
                 raise ValueError(f"{k} must be contiguous float32 [{want_t}, {self.N}, {self.A}, ...]")
         self.num_actions = num_actions
+        self._packed, self._packed_key = None, None
 
     @classmethod
     def from_trajectory(cls, traj, value_preds, returns, masks, action_log_probs, active_masks=None, **kw):
@@ -68,21 +69,28 @@ class MinibatchSource:
                 raise IndexError("permutation entries must lie in [0, batch_size)")
         return [perm[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(num_mini_batch)]   # :326-327
 
+    def _records(self, advantages):
+        """Sample records of the six scalar columns (+ advantages), rebuilt when any of them was written since."""
+        cols = [self.cols[k] for k in _SCALARS] + ([advantages] if advantages is not None else [])
+        key = tuple((t.data_ptr(), t._version) for t in cols)                   # in-place writes bump _version
+        if self._packed is None or self._packed_key != key:
+            rows = self.T * self.N * self.A
+            self._packed, self._packed_key = pack_columns(cols, rows), key
+        return self._packed
+
     def _batch(self, idx, obs_rows, advantages, row_mul, row_add, obs_dtype, norm_stats):
         obs_batch = gather_rows(self.obs.view(-1, *self.obs.shape[3:]), obs_rows, dtype=obs_dtype)
-        names = [k for k in _SCALARS + ("rnn_states", "rnn_states_critic", "available_actions") if self.cols[k] is not None]
-        tensors = [self.cols[k].view(-1, *self.cols[k].shape[3:]) for k in names]
-        stats = None
-        if advantages is not None:
-            names.append("adv_targ")
-            tensors.append(advantages.view(-1, *advantages.shape[3:]))
-            if norm_stats is not None:
-                stats = {len(tensors) - 1: norm_stats}
-        out = {}
-        for lo in range(0, len(names), 8):
-            part = gather_columns(tensors[lo:lo + 8], idx, row_mul, row_add,
-                                  {k - lo: v for k, v in (stats or {}).items() if lo <= k < lo + 8})
-            out.update(zip(names[lo:lo + 8], part))
+        if advantages is not None and (advantages.dtype != torch.float32 or not advantages.is_contiguous()
+                                       or advantages.numel() != self.T * self.N * self.A):
+            raise ValueError("advantages must be contiguous float32 [T, N, A, 1]")
+        n_cols = len(_SCALARS) + (advantages is not None)
+        vals = gather_records(self._records(advantages), n_cols, idx, row_mul, row_add,
+                              norm_col=len(_SCALARS) if (advantages is not None and norm_stats is not None) else -1,
+                              norm_stats=norm_stats)
+        out = dict(zip(_SCALARS + ("adv_targ",), vals))
+        wide = [k for k in ("rnn_states", "rnn_states_critic", "available_actions") if self.cols[k] is not None]
+        if wide:
+            out.update(zip(wide, gather_columns([self.cols[k].view(-1, *self.cols[k].shape[3:]) for k in wide], idx, row_mul, row_add)))
         avail = out.get("available_actions")
         if avail is None:
             avail = torch.ones((1, self.num_actions), dtype=torch.float32, device=self.obs.device).expand(idx.numel(), -1)

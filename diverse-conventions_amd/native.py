@@ -25,7 +25,7 @@ SYMBOLS = [
     "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
-    "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns",
+    "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
 
@@ -117,6 +117,8 @@ def lib():
     L.oc_gather_rows.argtypes = [vp, i64, ctypes.c_int32, vp, i64, vp, i32, vp]
     L.oc_gather_columns.argtypes = [ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32),
                                     ctypes.POINTER(vp), ctypes.POINTER(vp), vp, i64, i64, i64, vp]
+    L.oc_pack_columns.argtypes = [ctypes.c_int32, ctypes.POINTER(vp), i64, vp, vp]
+    L.oc_gather_records.argtypes = [vp, i64, ctypes.c_int32, ctypes.POINTER(vp), ctypes.c_int32, vp, vp, i64, i64, i64, vp]
     L.oc_last_error.argtypes = []
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_kernel_build_info.argtypes = [vp]

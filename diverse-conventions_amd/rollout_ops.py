@@ -148,3 +148,40 @@ def gather_columns(columns, index, row_mul=1, row_add=0, norm_stats=None, outs=N
         native.check(native.lib().oc_gather_columns(n_cols, src, rows, words, dst, stats, vp(index.data_ptr()), n, int(row_mul),
                                                     int(row_add), _stream(index)))
     return results
+
+
+def pack_columns(columns, n_rows):
+    """Interleave up to 8 one-word columns (contiguous 4-byte CUDA tensors with at least n_rows elements) into
+    sample records f32 [n_rows, 8]: one 32-byte sector per sample for `gather_records`."""
+    n_cols = len(columns)
+    if not 1 <= n_cols <= 8:
+        raise ValueError("1..8 columns per record")
+    vp = ctypes.c_void_p
+    src = (vp * n_cols)()
+    for c, t in enumerate(columns):
+        if t.element_size() != 4 or not t.is_cuda or not t.is_contiguous() or t.numel() < n_rows:
+            raise ValueError("columns must be contiguous 4-byte CUDA tensors of at least n_rows elements")
+        src[c] = t.data_ptr()
+    packed = torch.empty((n_rows, 8), dtype=torch.float32, device=columns[0].device)
+    native.check(native.lib().oc_pack_columns(n_cols, src, n_rows, vp(packed.data_ptr()), _stream(packed)))
+    return packed
+
+
+def gather_records(packed, n_cols, index, row_mul=1, row_add=0, norm_col=-1, norm_stats=None, dtypes=None):
+    """-> n_cols tensors [n, 1]: column c of records packed[index * row_mul + row_add]; `norm_col` is normalised with
+    `norm_stats` = {mean, std} while it is gathered."""
+    if packed.dtype != torch.float32 or packed.dim() != 2 or packed.shape[1] != 8 or not packed.is_contiguous():
+        raise ValueError("packed must come from pack_columns")
+    if index.dtype != torch.int64 or not index.is_cuda or not index.is_contiguous() or index.dim() != 1:
+        raise ValueError("index must be a contiguous 1-d int64 CUDA tensor")
+    n = index.numel()
+    vp = ctypes.c_void_p
+    outs = [torch.empty((n, 1), dtype=(dtypes[c] if dtypes else torch.float32), device=packed.device) for c in range(n_cols)]
+    dst = (vp * n_cols)(*[o.data_ptr() for o in outs])
+    if norm_col >= 0:
+        _f32_cuda("norm_stats", norm_stats)
+    if n:
+        native.check(native.lib().oc_gather_records(vp(packed.data_ptr()), packed.shape[0], n_cols, dst, norm_col,
+                                                    vp(norm_stats.data_ptr()) if norm_col >= 0 else None, vp(index.data_ptr()), n,
+                                                    int(row_mul), int(row_add), _stream(packed)))
+    return outs

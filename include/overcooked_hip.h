@@ -185,6 +185,15 @@ int oc_gather_rows(const void *d_src, int64_t src_rows, int32_t row_bytes, const
 int oc_gather_columns(int32_t n_cols, const void *const *d_src, const int64_t *src_rows, const int32_t *words, void *const *d_dst,
                       const float *const *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
                       void *stream);
+/* Sample records: oc_pack_columns interleaves n_cols (<= 8) one-word columns of n_rows rows into 32-byte records
+ * d_packed[n_rows][8] (once per update, streaming); oc_gather_records reads one record per sample -- one 32-byte
+ * sector instead of n_cols -- and writes the columns out separately and contiguously (d_dst: HOST array of n_cols
+ * device pointers, each [n_rows] words).  Row mapping as oc_gather_columns; norm_col >= 0 normalises that column
+ * with d_norm_stats = {mean, std} on the fly, -1 none. */
+int oc_pack_columns(int32_t n_cols, const void *const *d_src, int64_t n_rows, void *d_packed, void *stream);
+int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, void *const *d_dst, int32_t norm_col,
+                      const float *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
+                      void *stream);
 
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);

@@ -190,3 +190,19 @@ def test_large_normalisation_vs_float64():
     assert abs(float(stats[0]) - x.mean()) < 2e-6 and abs(float(stats[1]) - x.std(ddof=1)) < 2e-6
     ref = ((adv.cpu().numpy() - np.float32(x.mean())) / (np.float32(x.std(ddof=1)) + np.float32(1e-5)))
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_sample_records_follow_in_place_updates():
+    """The packed scalar records are a cache: a buffer written in place between two epochs must show up."""
+    import torch
+    i, c = CASES[0]
+    src = source_of(c)
+    adv = torch.from_numpy(gen_adv(c)).cuda()
+    first = [b[5].clone() for b in src.feed_forward_generator(adv, 3, perm=c["ff_perm"])]
+    src.cols["value_preds"].add_(1.0)
+    adv.mul_(2.0)
+    second = list(src.feed_forward_generator(adv, 3, perm=c["ff_perm"]))
+    for k, (a, b) in enumerate(zip(first, second)):
+        assert torch.equal(a + 1.0, b[5])
+        assert np.array_equal(b[10].cpu().numpy(), c["ff_adv_targ"][k] * 2.0)
