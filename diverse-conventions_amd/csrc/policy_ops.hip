@@ -1,0 +1,387 @@
+// policy_ops.hip -- fused policy inference on the CDNA4 matrix cores, gfx950.
+//
+// One launch evaluates every (row range, network) tile of a rollout step: all conventions' actors and critics,
+// both sides, every pairing segment -- the work the reference does as 2(2k+1) sequential CNN forwards of several
+// launches each (train/XD/xd_player.py:190-207, train/partner_agents.py:97-111, rMAPPOPolicy.get_actions).
+// Input rows are the engine's int8 observations exactly as oc_step wrote them ([rows][W][H][20], C fastest);
+// outputs are sampled actions (int32, the layout oc_step reads), their log-probabilities, and critic values.
+//
+// Network = reference CNNBase + Linear head (train/MAPPO/utils/cnn.py:12-60; hidden_size 64).  Per 32 rows:
+//   conv 3x3  : 6 x digits  v_mfma_i32_32x32x32_i8 per conv position.  Observations are small integers, so they
+//               are fed as int8 without conversion; the f32 weights are split once, at pack time, into `digits`
+//               base-128 fixed-point digits per output channel (policy_pack.h).  Integer accumulation is exact;
+//               with 4 digits the weight quantisation (2^-28 of the channel's largest weight) is below the f32
+//               rounding of the reference's own accumulation.
+//   fc1/fc2/head : v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-for-bit an fmaf chain.
+// Everything is evaluated transposed (feature index on the accumulator registers, row on the lanes): the output
+// of one layer is then directly the B operand of the next, with no lane movement and no LDS round trip.
+//
+// Bound: MFMA issue.  Cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 32*64) + 64*64 + 32*64;
+// cramped_room (P = 6, 4 digits) 23 040 cycles.  Bytes: rows are read once (W*H*20 B each).
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "overcooked_hip.h"
+#include "policy_pack.h"
+
+int oc_internal_fail(int code, const char *fmt, ...);      // overcooked_engine.hip: sets oc_last_error()
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load at 4-byte alignment
+
+constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
+constexpr int kMaxOut = 8;
+
+struct PolicyArgs {
+    const uint8_t *packed;              // [n_nets][L.total]
+    oc_policy_layout L;                 // section offsets, identical for every network of the launch
+    int n_nets;
+    const int8_t *obs;                  // [n_rows][RB]
+    long long n_rows;
+    int RB;                             // bytes per row = W*H*20
+    const int4 *tiles;                  // {row0, nrows, net, flags}
+    float *raw;                         // [n_rows][n_out] raw head outputs (tiles without OC_POLICY_TILE_ACT)
+    int32_t *actions;                   // [n_rows]
+    float *action_logp;                 // [n_rows]
+    float *logp;                        // [n_rows][n_out] or NULL
+    uint32_t seed, counter;
+    int sample;                         // 0: argmax, 1: Gumbel-max draw
+    int lds_wave_bytes;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
+    // accesses across the hand-over between "stage rows" and "read fragments"
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NDIG>
+__global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
+    extern __shared__ uint4 lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    uint8_t *ldsw = reinterpret_cast<uint8_t *>(lds_raw) + static_cast<size_t>(wave) * a.lds_wave_bytes;
+
+    const int4 tile = a.tiles[blockIdx.x];
+    long long row0 = tile.x;
+    int nrows = tile.y;
+    const int net = min(max(tile.z, 0), a.n_nets - 1);
+    const int flags = tile.w;
+    if (row0 < 0 || row0 >= a.n_rows) return;                         // a bad tile does nothing
+    if (row0 + nrows > a.n_rows) nrows = static_cast<int>(a.n_rows - row0);
+
+    const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
+    const int n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
+    const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
+
+    // conv weight digits live in registers for the whole tile: [kx*2+s][digit] x 16 bytes per lane
+    v4i wA[6][NDIG];
+    {
+        const v4i *src = reinterpret_cast<const v4i *>(blob + a.L.off_conv);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
+    }
+    float csc[16], cbi[16];
+    {
+        const float *sb = reinterpret_cast<const float *>(blob + a.L.off_conv_sb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
+    }
+    const float *w1 = reinterpret_cast<const float *>(blob + a.L.off_fc1);
+    const float *b1 = reinterpret_cast<const float *>(blob + a.L.off_b1);
+    const float *w2 = reinterpret_cast<const float *>(blob + a.L.off_fc2);
+    const float *b2 = reinterpret_cast<const float *>(blob + a.L.off_b2);
+    const float *wh = reinterpret_cast<const float *>(blob + a.L.off_head);
+    const float *bh = reinterpret_cast<const float *>(blob + a.L.off_bh);
+
+    const long long obs_bytes = a.n_rows * RB;
+    const int n16 = 2 * RB;                                           // 16-byte pieces in 32 rows
+
+    for (int blk = wave; blk * kRowsPerBlock < nrows; blk += nwaves) {
+        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
+        // ---- stage 32 rows: one flat copy, the LDS image is the HBM block verbatim ----
+        wave_lds_sync();
+        {
+            const long long base = brow * RB;
+            for (int i = lane; i < n16; i += 64) {
+                long long off = base + 16ll * i;
+                off = off > obs_bytes - 16 ? obs_bytes - 16 : off;    // rows past the end: any valid bytes will do
+                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(a.obs + off);
+                reinterpret_cast<uint4 *>(ldsw)[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+        wave_lds_sync();
+
+        v16f h1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[m][r] = 0.f;
+
+        const uint8_t *rowp = ldsw + col * RB + 16 * h;
+        int xq = 0, yq = 0;                                           // conv position p = xq * PH + yq
+        for (int p = 0; p < P; ++p) {
+            // ---- conv at position p: X^T[o][row] for the 32 rows ----
+            v16i acc[NDIG];
+#pragma unroll
+            for (int d = 0; d < NDIG; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const uint8_t *slab = rowp + ((xq + kx) * H + yq) * OC_POLICY_C;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(slab + 32 * s);
+                    v4i b;
+                    b.x = static_cast<int>(q[0]); b.y = static_cast<int>(q[1]);
+                    b.z = static_cast<int>(q[2]); b.w = static_cast<int>(q[3]);
+#pragma unroll
+                    for (int d = 0; d < NDIG; ++d)
+                        acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[kx * 2 + s][d], b, acc[d], 0, 0, 0);
+                }
+            }
+            v16f x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = static_cast<float>(acc[0][r]);
+#pragma unroll
+                for (int d = 1; d < NDIG; ++d) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[d][r]));
+                x[r] = fmaxf(__builtin_fmaf(t, csc[r], cbi[r]), 0.f);
+            }
+            // ---- fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row] ----
+            const float *w1p = w1 + static_cast<size_t>(p) * 2048 + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    h1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1p[(m * 16 + s) * 64], x[s], h1[m], 0, 0, 0);
+            if (++yq == PH) { yq = 0; ++xq; }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[m][r] = fmaxf(h1[m][r] + b1[(m * 2 + h) * 16 + r], 0.f);
+
+        // ---- fc2 ----
+        v16f h2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[m][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+                    h2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[((m2 * 2 + m) * 16 + s) * 64 + lane], h1[m][s], h2[m2], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[m][r] = fmaxf(h2[m][r] + b2[(m * 2 + h) * 16 + r], 0.f);
+
+        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3 ----
+        v16f out;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(m * 16 + s) * 64 + lane], h2[m][s], out, 0, 0, 0);
+
+        float l[kMaxOut];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mine = out[r] + bh[h * 4 + r];
+            const float other = __shfl_xor(mine, 32);
+            l[r] = h ? other : mine;
+            l[r + 4] = h ? mine : other;
+        }
+        const long long row = brow + col;
+        const bool valid = h == 0 && (blk * kRowsPerBlock + col) < nrows;
+        if (!(flags & OC_POLICY_TILE_ACT)) {
+            if (valid && a.raw) {
+#pragma unroll
+                for (int i = 0; i < kMaxOut; ++i)
+                    if (i < n_out) a.raw[row * n_out + i] = l[i];
+            }
+            continue;
+        }
+        // ---- actor epilogue: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80),
+        //      then argmax (mode) or a Gumbel-max draw ----
+        float mx = l[0];
+#pragma unroll
+        for (int i = 1; i < kMaxOut; ++i)
+            if (i < n_out) mx = fmaxf(mx, l[i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxOut; ++i)
+            if (i < n_out) sum += expf(l[i] - mx);
+        const float lse = mx + logf(sum);
+        int best = 0;
+        float best_key = -INFINITY, best_lp = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxOut; ++i) {
+            if (i < n_out) {
+                const float lp = l[i] - lse;
+                float key = lp;
+                if (a.sample) {
+                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, a.counter, static_cast<uint32_t>(row), i));
+                    key = lp - logf(-logf(u));
+                }
+                if (key > best_key) { best_key = key; best = i; best_lp = lp; }
+                if (valid && a.logp) a.logp[row * n_out + i] = lp;
+            }
+        }
+        if (valid) {
+            if (a.actions) a.actions[row] = best;
+            if (a.action_logp) a.action_logp[row] = best_lp;
+        }
+    }
+}
+
+__global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
+    const long long words = L.total / 4;
+    for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < words;
+         i += static_cast<long long>(gridDim.x) * blockDim.x)
+        dst[i] = oc_policy_pack_word(L, w, i);
+}
+
+int check_shape(const oc_policy_shape *s, const char *who) {
+    if (!s) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: shape is NULL", who);
+    if (s->width < 3 || s->height < 3 || s->width * s->height > OC_MAX_TILES)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: grid %dx%d outside 3x3 .. %d tiles", who, s->width, s->height, OC_MAX_TILES);
+    if (s->hidden != OC_POLICY_HID)
+        return oc_internal_fail(OC_ERR_UNSUPPORTED, "%s: hidden_size %d (the fused kernel is built for %d, the reference's training setting)",
+                                who, s->hidden, OC_POLICY_HID);
+    if (s->n_out < 1 || s->n_out > kMaxOut) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: n_out %d outside 1..%d", who, s->n_out, kMaxOut);
+    if (s->digits < 1 || s->digits > 4) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: digits %d outside 1..4", who, s->digits);
+    return OC_OK;
+}
+
+bool any_null(const oc_policy_weights &w) {
+    return !w.conv_w || !w.conv_b || !w.fc1_w || !w.fc1_b || !w.fc2_w || !w.fc2_b || !w.head_w || !w.head_b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t oc_policy_packed_bytes(const oc_policy_shape *shape) {
+    if (check_shape(shape, "oc_policy_packed_bytes") != OC_OK) return -1;
+    return oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out).total;
+}
+
+int oc_policy_pack_host(const oc_policy_shape *shape, const float *conv_w, const float *conv_b, const float *fc1_w,
+                        const float *fc1_b, const float *fc2_w, const float *fc2_b, const float *head_w, const float *head_b,
+                        void *host_dst) {
+    if (int rc = check_shape(shape, "oc_policy_pack_host")) return rc;
+    const oc_policy_weights w = {conv_w, conv_b, fc1_w, fc1_b, fc2_w, fc2_b, head_w, head_b};
+    if (any_null(w) || !host_dst) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_pack_host: NULL pointer");
+    const oc_policy_layout L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
+    uint32_t *dst = static_cast<uint32_t *>(host_dst);
+    for (int64_t i = 0; i < L.total / 4; ++i) dst[i] = oc_policy_pack_word(L, w, i);
+    return OC_OK;
+}
+
+int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const float *d_conv_b, const float *d_fc1_w,
+                   const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b, const float *d_head_w,
+                   const float *d_head_b, void *d_dst, void *stream) {
+    if (int rc = check_shape(shape, "oc_policy_pack")) return rc;
+    const oc_policy_weights w = {d_conv_w, d_conv_b, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_head_w, d_head_b};
+    if (any_null(w) || !d_dst) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_pack: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(d_dst) & 15) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_pack: d_dst must be 16-byte aligned");
+    const oc_policy_layout L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
+    const unsigned grid = static_cast<unsigned>((L.total / 4 + 255) / 256);
+    hipLaunchKernelGGL(oc_policy_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), L, w,
+                       static_cast<uint32_t *>(d_dst));
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_pack: launch failed: %s", hipGetErrorString(err));
+    return OC_OK;
+}
+
+int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
+                             int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity) {
+    if (!seg_row0 || !seg_rows || !seg_net || n_segs < 0 || rows_per_tile < kRowsPerBlock || rows_per_tile % kRowsPerBlock)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: bad arguments (rows_per_tile must be a multiple of %d)", kRowsPerBlock);
+    int64_t n = 0;
+    for (int32_t g = 0; g < n_segs; ++g) {
+        if (seg_row0[g] < 0 || seg_rows[g] < 0 || seg_row0[g] + seg_rows[g] > INT32_MAX)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: segment %d out of range", g);
+        for (int64_t r = 0; r < seg_rows[g]; r += rows_per_tile, ++n) {
+            if (!host_tiles) continue;
+            if (n >= capacity) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: capacity %lld too small", (long long)capacity);
+            const int64_t left = seg_rows[g] - r;
+            host_tiles[4 * n + 0] = static_cast<int32_t>(seg_row0[g] + r);
+            host_tiles[4 * n + 1] = static_cast<int32_t>(left < rows_per_tile ? left : rows_per_tile);
+            host_tiles[4 * n + 2] = seg_net[g];
+            host_tiles[4 * n + 3] = seg_flags ? seg_flags[g] : 0;
+        }
+    }
+    return n;
+}
+
+int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                      const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, void *stream) {
+    if (int rc = check_shape(shape, "oc_policy_forward")) return rc;
+    if (!d_packed || !d_obs || !d_tiles || n_nets < 1 || n_rows < 1 || n_tiles < 0)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
+    if ((reinterpret_cast<uintptr_t>(d_packed) & 15) || (reinterpret_cast<uintptr_t>(d_obs) & 3) || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_packed / d_tiles must be 16-byte aligned, d_obs 4-byte aligned");
+    if (n_rows > INT32_MAX) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: more than 2^31 rows");
+    if (sample_mode != 0 && sample_mode != 1) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: sample_mode %d", sample_mode);
+    if (n_tiles == 0) return OC_OK;
+    PolicyArgs a;
+    a.packed = static_cast<const uint8_t *>(d_packed);
+    a.L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
+    a.n_nets = n_nets;
+    a.obs = d_obs;
+    a.n_rows = n_rows;
+    a.RB = shape->width * shape->height * OC_POLICY_C;
+    if (n_rows * a.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
+    a.tiles = reinterpret_cast<const int4 *>(d_tiles);
+    a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
+    a.seed = seed; a.counter = counter; a.sample = sample_mode;
+    a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
+    int waves = 4;
+    while (waves > 1 && static_cast<long long>(waves) * a.lds_wave_bytes > 160 * 1024) waves >>= 1;
+    const size_t lds = static_cast<size_t>(waves) * a.lds_wave_bytes;
+    if (lds > 160 * 1024) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
+    void (*kernel)(const PolicyArgs) = nullptr;
+    switch (shape->digits) {
+        case 1: kernel = oc_policy_kernel<1>; break;
+        case 2: kernel = oc_policy_kernel<2>; break;
+        case 3: kernel = oc_policy_kernel<3>; break;
+        default: kernel = oc_policy_kernel<4>; break;
+    }
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
+    return OC_OK;
+}
+
+float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action) {
+    return oc_policy_uniform_from_hash(oc_policy_hash(seed, counter, row, action));
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Fused policy inference: front-end of `oc_policy_forward`.
+
+The reference walks the pairing segments and calls `policy.get_actions` -- an R_Actor and an R_Critic forward of
+several launches each -- once per segment and side (train/XD/xd_player.py:190-207, train/partner_agents.py:97-111).
+Here every network of a rollout step (all conventions' actors and critics, both sides) is one tile list for ONE
+launch of a hand-written MFMA kernel that reads the engine's int8 observations and writes the int32 actions the
+step kernel reads.  `PackedNetworks` holds the networks in the kernel's weight image (packed on the device,
+stream-ordered, so it can follow an optimiser step); `PolicyPlan` is the tile list for a fixed segment -> network
+map.  There is no fallback: without the HIP library these classes raise.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import native
+
+ACTOR_HEAD = "act.action_out.linear"        # reference utils/act.py + distributions.py:60-80
+CRITIC_HEAD = "v_out"                       # reference r_actor_critic.py:165
+TILE_ACT = 1                                # OC_POLICY_TILE_ACT
+
+_KEYS = ("base.cnn.cnn.0.weight", "base.cnn.cnn.0.bias", "base.cnn.cnn.3.weight", "base.cnn.cnn.3.bias",
+         "base.cnn.cnn.5.weight", "base.cnn.cnn.5.bias")
+
+
+def _shape(width, height, n_out, digits, hidden=64):
+    return native.OcPolicyShape(int(width), int(height), int(hidden), int(n_out), int(digits))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def packed_bytes(width, height, digits=4):
+    n = native.lib().oc_policy_packed_bytes(ctypes.byref(_shape(width, height, 1, digits)))
+    if n < 0:
+        native.check(int(n))
+    return int(n)
+
+
+def pack_host(state_dict, obs_shape, head=ACTOR_HEAD, digits=4) -> np.ndarray:
+    """Weight image of one reference-format network as a uint8 array (host packer; tests, inspection)."""
+    W, H = int(obs_shape[0]), int(obs_shape[1])
+    arrs = [np.ascontiguousarray(np.asarray(state_dict[k], dtype=np.float32)) for k in _KEYS]
+    arrs += [np.ascontiguousarray(np.asarray(state_dict[head + s], dtype=np.float32)) for s in (".weight", ".bias")]
+    hidden = arrs[4].shape[0]
+    out = np.zeros(packed_bytes(W, H, digits), dtype=np.uint8)
+    native.check(native.lib().oc_policy_pack_host(ctypes.byref(_shape(W, H, arrs[6].shape[0], digits, hidden)),
+                                                  *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs],
+                                                  out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+class PackedNetworks:
+    """`n_nets` networks of one observation shape in the kernel's weight image, resident in HBM.
+
+    `pack(i, state_dict, head)` converts reference-format tensors (host or device) on the device; call it again
+    after every optimiser step for the networks that changed."""
+
+    def __init__(self, obs_shape, n_nets, device, digits=4):
+        self.W, self.H = int(obs_shape[0]), int(obs_shape[1])
+        if len(obs_shape) > 2 and int(obs_shape[2]) != 20:
+            raise ValueError("the fused kernel reads the engine's 20-channel observations")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("PackedNetworks lives on the GPU (the fused policy kernel has no CPU path)")
+        self.digits, self.n_nets = int(digits), int(n_nets)
+        self.bytes_per_net = packed_bytes(self.W, self.H, self.digits)
+        self.image = torch.zeros((self.n_nets, self.bytes_per_net), dtype=torch.uint8, device=self.device)
+        self.n_out = [0] * self.n_nets
+        self._keep = {}
+
+    def pack(self, index, state_dict, head=ACTOR_HEAD):
+        t = lambda k: torch.as_tensor(state_dict[k]).detach().to(device=self.device, dtype=torch.float32).contiguous()
+        src = [t(k) for k in _KEYS] + [t(head + ".weight"), t(head + ".bias")]
+        hidden, n_out = src[4].shape[0], src[6].shape[0]
+        P = (self.W - 2) * (self.H - 2)
+        if tuple(src[0].shape) != (hidden // 2, 20, 3, 3) or tuple(src[2].shape) != (hidden, hidden // 2 * P):
+            raise ValueError(f"network {index} does not have the reference CNNBase shape for a {self.W}x{self.H} grid")
+        self._keep[index] = src                      # the pack kernel reads them asynchronously
+        native.check(native.lib().oc_policy_pack(ctypes.byref(_shape(self.W, self.H, n_out, self.digits, hidden)),
+                                                 *[_ptr(x) for x in src], _ptr(self.image[index]), _stream(self.device)))
+        self.n_out[index] = n_out
+        return index
+
+    @classmethod
+    def from_state_dicts(cls, obs_shape, device, actors: Sequence[dict] = (), critics: Sequence[dict] = (), digits=4):
+        """Actors get indices 0..len(actors)-1, critics follow."""
+        nets = cls(obs_shape, len(actors) + len(critics), device, digits)
+        for i, sd in enumerate(actors):
+            nets.pack(i, sd, ACTOR_HEAD)
+        for i, sd in enumerate(critics):
+            nets.pack(len(actors) + i, sd, CRITIC_HEAD)
+        return nets
+
+
+def plan_tiles(segments, rows_per_tile):
+    """segments: iterable of (row0, rows, net, flags) -> int32 [n_tiles, 4] host tensor (oc_policy_plan_tiles)."""
+    seg = np.asarray(list(segments), dtype=np.int64).reshape(-1, 4)
+    row0, rows = np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1])
+    net, flags = np.ascontiguousarray(seg[:, 2].astype(np.int32)), np.ascontiguousarray(seg[:, 3].astype(np.int32))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    L = native.lib()
+    n = L.oc_policy_plan_tiles(p(row0), p(rows), p(net), p(flags), len(seg), int(rows_per_tile), None, 0)
+    if n < 0:
+        native.check(int(n))
+    tiles = np.zeros((max(int(n), 1), 4), dtype=np.int32)
+    n2 = L.oc_policy_plan_tiles(p(row0), p(rows), p(net), p(flags), len(seg), int(rows_per_tile), p(tiles), int(n))
+    if n2 < 0:
+        native.check(int(n2))
+    return torch.from_numpy(tiles[:int(n)])
+
+
+class PolicyPlan:
+    """Tile list for a fixed (row range -> network) map over `n_rows` observation rows.
+
+    segments: (row0, rows, net, flags); flags TILE_ACT = actor epilogue (actions + log-probs), 0 = raw head outputs
+    (critic values).  Rows are flat indices into the engine's `[P, N]` leading axes: row = player * N + kitchen."""
+
+    def __init__(self, nets: PackedNetworks, n_rows: int, segments, rows_per_tile: Optional[int] = None):
+        self.nets, self.n_rows = nets, int(n_rows)
+        segments = [tuple(int(v) for v in s) for s in segments]
+        for row0, rows, net, _ in segments:
+            if row0 < 0 or rows < 0 or row0 + rows > self.n_rows or not 0 <= net < nets.n_nets:
+                raise ValueError(f"segment ({row0}, {rows}, net {net}) outside {self.n_rows} rows / {nets.n_nets} networks")
+        if rows_per_tile is None:
+            # about two workgroups per CU, each long enough to amortise its weight loads
+            total = sum(s[1] for s in segments)
+            cus = torch.cuda.get_device_properties(nets.device).multi_processor_count
+            want = -(-total // (2 * cus))
+            rows_per_tile = max(128, min(2048, -(-want // 128) * 128))
+        self.rows_per_tile = int(rows_per_tile)
+        self.tiles = plan_tiles(segments, self.rows_per_tile).to(nets.device)
+        self.n_tiles = int(self.tiles.shape[0])
+        self.counter = 0
+
+    def forward(self, obs, raw=None, actions=None, action_logp=None, logp=None, deterministic=False, seed=0, counter=None):
+        """obs: contiguous int8 tensor whose leading axes flatten to n_rows rows of W*H*20 bytes."""
+        nets = self.nets
+        rb = nets.W * nets.H * 20
+        if obs.dtype != torch.int8 or not obs.is_contiguous() or obs.device != nets.device or obs.numel() != self.n_rows * rb:
+            raise ValueError(f"obs must be a contiguous int8 tensor of {self.n_rows} rows x {rb} bytes on {nets.device}")
+        for name, t, dt in (("raw", raw, torch.float32), ("actions", actions, torch.int32),
+                            ("action_logp", action_logp, torch.float32), ("logp", logp, torch.float32)):
+            if t is not None and (t.dtype != dt or not t.is_contiguous() or t.device != nets.device):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor on {nets.device}")
+        if counter is None:
+            counter, self.counter = self.counter, self.counter + 1
+        shape = _shape(nets.W, nets.H, 6, nets.digits)
+        native.check(native.lib().oc_policy_forward(ctypes.byref(shape), _ptr(nets.image), nets.n_nets, _ptr(obs), self.n_rows,
+                                                    _ptr(self.tiles), self.n_tiles, _ptr(raw), _ptr(actions), _ptr(action_logp),
+                                                    _ptr(logp), 0 if deterministic else 1, int(seed) & 0xFFFFFFFF,
+                                                    int(counter) & 0xFFFFFFFF, _stream(nets.device)))
+
+
+def gumbel_uniform(seed, counter, row, action):
+    """The uniform the kernel used for (row, action) of a draw: lets a test re-derive every sampled action."""
+    return float(native.lib().oc_policy_uniform(int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, int(row), int(action)))

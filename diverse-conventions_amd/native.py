@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
-SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip")]
+SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
+           os.path.join(CSRC, "policy_ops.hip")]
+HEADERS = [os.path.join(CSRC, "policy_pack.h")]
 KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")
 KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: KERNEL_HEADER as a C++ raw string
 INCLUDE = os.path.join(REPO_ROOT, "include")
@@ -26,8 +28,15 @@ SYMBOLS = [
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
+    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_uniform",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
+
+
+class OcPolicyShape(ctypes.Structure):
+    """struct oc_policy_shape"""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("hidden", ctypes.c_int32),
+                ("n_out", ctypes.c_int32), ("digits", ctypes.c_int32)]
 
 
 class OcLayoutParams(ctypes.Structure):
@@ -50,7 +59,7 @@ class OvercookedNativeError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + [KERNEL_HEADER, os.path.join(INCLUDE, "overcooked_hip.h")])
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, os.path.join(INCLUDE, "overcooked_hip.h")])
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     # the kernel header is also embedded as text: oc_create() re-compiles it per engine with hiprtc
@@ -119,6 +128,16 @@ def lib():
                                     ctypes.POINTER(vp), ctypes.POINTER(vp), vp, i64, i64, i64, vp]
     L.oc_pack_columns.argtypes = [ctypes.c_int32, ctypes.POINTER(vp), i64, vp, vp]
     L.oc_gather_records.argtypes = [vp, i64, ctypes.c_int32, ctypes.POINTER(vp), ctypes.c_int32, vp, vp, i64, i64, i64, vp]
+    ps = ctypes.POINTER(OcPolicyShape)
+    L.oc_policy_packed_bytes.argtypes = [ps]
+    L.oc_policy_packed_bytes.restype = i64
+    L.oc_policy_pack_host.argtypes = [ps] + [vp] * 9
+    L.oc_policy_pack.argtypes = [ps] + [vp] * 10
+    L.oc_policy_plan_tiles.argtypes = [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, i64]
+    L.oc_policy_plan_tiles.restype = i64
+    L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp]
+    L.oc_policy_uniform.argtypes = [u32, u32, u32, u32]
+    L.oc_policy_uniform.restype = ctypes.c_float
     L.oc_last_error.argtypes = []
     L.oc_last_error.restype = ctypes.c_char_p
     L.oc_kernel_build_info.argtypes = [vp]

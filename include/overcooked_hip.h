@@ -195,6 +195,54 @@ int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, vo
                       const float *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
                       void *stream);
 
+/* ---- fused policy inference on the matrix cores --------------------------------------------
+ * One launch evaluates every (row range, network) tile of a rollout step -- all conventions' actors and critics,
+ * both sides, every pairing segment -- reading the int8 observations oc_step wrote and writing the int32 actions
+ * oc_step reads.  Replaces the per-segment loops over policy.get_actions (train/XD/xd_player.py:190-207,
+ * train/partner_agents.py:97-111; rMAPPOPolicy.get_actions = R_Actor.forward + R_Critic.forward,
+ * train/MAPPO/r_actor_critic.py:57-76,175-199) for the reference architecture: CNNBase (utils/cnn.py:12-60: conv 3x3
+ * valid 20 -> hidden/2, ReLU, flatten, Linear -> hidden, ReLU, Linear -> hidden, ReLU) + one Linear head
+ * (6 action logits, utils/act.py + distributions.py:60-80, or 1 value, `v_out`).  hidden_size 64 (train_xp.sh:12);
+ * other sizes return OC_ERR_UNSUPPORTED.  Numerics: conv in exact integer arithmetic on `digits` base-128
+ * fixed-point weight digits (4: quantisation 2^-28 of each channel's largest weight), dense layers on f32-input
+ * MFMA (an fmaf chain); outputs agree with the reference's f32 forward to ~1e-6. */
+typedef struct {
+    int32_t width, height;     /* observation grid; rows are width*height*20 int8, C fastest, W before H */
+    int32_t hidden;            /* reference --hidden_size: 64 */
+    int32_t n_out;             /* head outputs of the network being packed: 1..8 (6 logits / 1 value) */
+    int32_t digits;            /* conv weight digits 1..4 (7, 14, 21, 28 bits) */
+} oc_policy_shape;
+
+#define OC_POLICY_TILE_ACT 1   /* tile flag: actor epilogue (log-softmax, action draw); otherwise raw head outputs */
+
+/* Bytes of one packed network (a function of width, height, digits only; multiple of 256). < 0 on error. */
+int64_t oc_policy_packed_bytes(const oc_policy_shape *shape);
+/* Pack one network from the reference's state-dict tensors (f32, contiguous): conv_w [32][20][3][3]
+ * (base.cnn.cnn.0.weight), conv_b [32], fc1_w [64][32*(W-2)*(H-2)] (base.cnn.cnn.3), fc1_b, fc2_w [64][64]
+ * (base.cnn.cnn.5), fc2_b, head_w [n_out][64] (act.action_out.linear / v_out), head_b.  _host: host pointers,
+ * synchronous (tests, C clients); the other: device pointers, stream-ordered (after an optimiser step). */
+int oc_policy_pack_host(const oc_policy_shape *shape, const float *conv_w, const float *conv_b, const float *fc1_w,
+                        const float *fc1_b, const float *fc2_w, const float *fc2_b, const float *head_w, const float *head_b,
+                        void *host_dst);
+int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const float *d_conv_b, const float *d_fc1_w,
+                   const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b, const float *d_head_w,
+                   const float *d_head_b, void *d_dst, void *stream);
+/* Cut segments (row0, rows, network index, flags) into workgroup tiles of at most rows_per_tile rows (multiple of
+ * 32): host_tiles int32 [capacity][4] = {row0, rows, net, flags}.  Returns the tile count (host_tiles may be NULL
+ * to ask for it), < 0 on error.  Pairing segments: train/XD/serial.py:27, xd_player.py:76-77,94. */
+int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
+                             int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity);
+/* d_packed: n_nets packed networks of this shape (n_out may differ per network; it is read from each image),
+ * d_obs int8 [n_rows][W][H][20], d_tiles int32 [n_tiles][4] on the device.  Tiles without OC_POLICY_TILE_ACT write
+ * d_raw[row * n_out + a] (raw head outputs: critic values, or logits); tiles with it write d_actions[row] (int32),
+ * d_action_logp[row] and, if non-NULL, d_logp[row * n_out + a] (normalised log-probabilities).  sample_mode 0 =
+ * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter, row, a).
+ * Rows and network indices of a bad tile are clamped; any output pointer may be NULL. */
+int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                      const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, void *stream);
+float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
+
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);
 int oc_obs_shape(const oc_engine *e, int64_t shape5[5]);   /* P, N, W, H, C */

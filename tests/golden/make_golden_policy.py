@@ -57,6 +57,23 @@ if __name__ == "__main__":
         for name, t in critic.state_dict().items():
             out[f"c{k}.{name}"] = t.numpy()
         out[f"c{k}.values"] = values.numpy()
+    # a second grid shape (unident_s, 9x5 -> 7x3 conv positions) pins the Flatten order (o, x', y') where W-2 != H-2 != 2
+    obs2 = np.load(os.path.join(HERE, "guided_unident_s.npz"))["obs"][::5].reshape(-1, 9, 5, 20)[:96]
+    out2 = {"obs": obs2}
+    torch.manual_seed(300)
+    actor = R_Actor(args, Space((9, 5, 20)), Discrete(n=6))
+    critic = R_Critic(args, Space((9, 5, 20)))
+    with torch.no_grad():
+        for p in list(actor.parameters()) + list(critic.parameters()):
+            p.add_(torch.randn_like(p) * 0.05)
+        x2 = torch.from_numpy(obs2).float()
+        out2["a0.logits"] = actor.act.action_out(actor.base(x2)).logits.numpy()
+        out2["c0.values"] = critic(x2, torch.zeros(len(obs2), 1, 64), torch.ones(len(obs2), 1))[0].numpy()
+    for name, t in actor.state_dict().items():
+        out2[f"a0.{name}"] = t.numpy()
+    for name, t in critic.state_dict().items():
+        out2[f"c0.{name}"] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "policy_cases_unident_s.npz"), **out2)
     np.savez_compressed(os.path.join(HERE, "policy_cases.npz"), **out)
     print("wrote policy_cases.npz", os.path.getsize(os.path.join(HERE, "policy_cases.npz")) // 1024, "KiB",
           [k for k in out if k.startswith("a0.")])

@@ -1,0 +1,250 @@
+"""Fused MFMA policy inference (oc_policy_forward) against the reference's R_Actor / R_Critic.
+
+Oracle chain: tests/golden/policy_cases*.npz hold outputs of the reference modules themselves (two grid shapes);
+oracle/policy_oracle.reference_forward is the numpy restatement pinned to them; emulate_packed replays the kernel's
+lane-level dataflow on the packed weight image (CPU).  Floating point: the kernel's head outputs must be within
+TOL = 2e-6 absolute of the reference's float32 forward with 4 weight digits (the summation order differs from
+torch's GEMM; the f32 MFMA is an fmaf chain, the conv is exact integer arithmetic); deterministic actions equal."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from diverse_conventions_amd import native
+from diverse_conventions_amd.fused_policy import (ACTOR_HEAD, CRITIC_HEAD, TILE_ACT, PackedNetworks, PolicyPlan, gumbel_uniform,
+                                                  pack_host, packed_bytes, plan_tiles)
+from oracle.policy_oracle import emulate_packed, log_softmax, parse_image, reference_forward
+
+TOL = 2e-6
+TOL_LOGP = 4e-6          # log-softmax adds one expf/logf round trip
+
+
+def cases(name="policy_cases.npz"):
+    z = np.load(os.path.join(GOLDEN, name))
+    get = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and "weight" in k or k.startswith(pre) and "bias" in k}
+    return z, get
+
+
+def random_net(W, H, n_out, head, seed):
+    rng = np.random.default_rng(seed)
+    P = (W - 2) * (H - 2)
+    r = lambda *s: (rng.standard_normal(s) * 0.12).astype(np.float32)
+    return {"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+            "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64),
+            head + ".weight": r(n_out, 64), head + ".bias": r(n_out)}
+
+
+# ------------------------------------------------------------------------------------------- CPU: oracle, packing
+def test_oracle_matches_reference_outputs():
+    z, get = cases()
+    for i in range(3):
+        out = reference_forward(get(f"a{i}."), z["obs"], ACTOR_HEAD)
+        assert np.abs(log_softmax(out) - z[f"a{i}.logits"]).max() < 1e-6
+        assert np.array_equal(out.argmax(-1)[:, None], z[f"a{i}.det_action"])
+    for i in range(2):
+        assert np.abs(reference_forward(get(f"c{i}."), z["obs"], CRITIC_HEAD) - z[f"c{i}.values"]).max() < 1e-6
+    z, get = cases("policy_cases_unident_s.npz")
+    assert np.abs(log_softmax(reference_forward(get("a0."), z["obs"], ACTOR_HEAD)) - z["a0.logits"]).max() < 1e-6
+    assert np.abs(reference_forward(get("c0."), z["obs"], CRITIC_HEAD) - z["c0.values"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("digits,tol", [(4, 1e-6), (3, 3e-6), (2, 3e-4)])
+def test_packed_image_emulation_matches_reference(digits, tol):
+    """Host packer + lane-level emulation of the kernel's MFMA dataflow == reference outputs (no GPU involved)."""
+    z, get = cases()
+    blob = pack_host(get("a1."), (5, 4, 20), ACTOR_HEAD, digits)
+    meta, _ = parse_image(blob)
+    assert meta == dict(W=5, H=4, n_out=6, digits=digits, P=6) and len(blob) == packed_bytes(5, 4, digits)
+    out = emulate_packed(blob, z["obs"][:48].reshape(48, -1))
+    assert np.abs(log_softmax(out) - z["a1.logits"][:48]).max() < tol
+    if digits == 4:
+        blob = pack_host(get("c1."), (5, 4, 20), CRITIC_HEAD, 4)
+        assert np.abs(emulate_packed(blob, z["obs"][100:133].reshape(33, -1)) - z["c1.values"][100:133]).max() < tol
+
+
+def test_packed_image_emulation_second_grid():
+    z, get = cases("policy_cases_unident_s.npz")
+    out = emulate_packed(pack_host(get("a0."), (9, 5, 20), ACTOR_HEAD, 4), z["obs"][:33].reshape(33, -1))
+    assert np.abs(log_softmax(out) - z["a0.logits"][:33]).max() < 2e-6
+
+
+def test_conv_digits_reconstruct_weights():
+    sd = random_net(5, 4, 6, ACTOR_HEAD, 3)
+    sd["base.cnn.cnn.0.weight"][7] = 0                      # an all-zero channel must not divide by zero
+    for digits in (1, 2, 3, 4):
+        _, sec = parse_image(pack_host(sd, (5, 4, 20), ACTOR_HEAD, digits))
+        conv, sb = sec["conv"].astype(np.int64), sec["conv_sb"]
+        assert np.abs(conv[:, 0]).max() <= 127 and (digits == 1 or (conv[:, 1:].min() >= -64 and conv[:, 1:].max() <= 63))
+        q = sum(conv[:, d] * 128 ** (digits - 1 - d) for d in range(digits))          # [6][64][16]
+        w = sd["base.cnn.cnn.0.weight"]
+        for o in (0, 7, 31):
+            lane_h0, lane_h1 = o, 32 + o
+            reg, h = [(r, hh) for r in range(16) for hh in range(2) if (r & 3) + 8 * (r >> 2) + 4 * hh == o][0]
+            scale = sb[0][h][reg]
+            for kx in range(3):
+                k = np.concatenate([q[kx * 2 + s, lane] for s in range(2) for lane in (lane_h0, lane_h1)])   # k 0..63
+                want = w[o, :, kx, :].T.reshape(-1)                                     # (ky, c) order, 60 values
+                assert np.all(k[60:] == 0)
+                step = np.abs(w[o]).max() / (126 * 128 ** (digits - 1))               # + the f32 rounding of `scale`
+                assert np.abs(k[:60] * np.float64(scale) - want).max() <= 0.51 * step + 2e-7 * np.abs(w[o]).max() + 1e-12
+
+
+def test_abi_argument_checks_and_tile_plan():
+    L = native.lib()
+    S = native.OcPolicyShape
+    assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 64, 6, 4))) == packed_bytes(5, 4, 4) > 0
+    assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 128, 6, 4))) < 0 and b"hidden_size" in L.oc_last_error()
+    assert L.oc_policy_packed_bytes(ctypes.byref(S(2, 4, 64, 6, 4))) < 0
+    assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 64, 9, 4))) < 0
+    assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 64, 6, 5))) < 0
+    assert L.oc_policy_forward(ctypes.byref(S(5, 4, 64, 6, 4)), None, 1, None, 10, None, 1, None, None, None, None, 0, 0, 0, None) == -1
+    t = plan_tiles([(0, 300, 2, TILE_ACT), (300, 64, 5, 0), (364, 0, 1, 0)], 128).numpy()
+    assert t.tolist() == [[0, 128, 2, 1], [128, 128, 2, 1], [256, 44, 2, 1], [300, 64, 5, 0]]
+    with pytest.raises(native.OvercookedNativeError):
+        plan_tiles([(0, 10, 0, 0)], 100)                     # not a multiple of 32
+
+
+def test_uniform_hash_is_open_interval_and_spread():
+    u = np.array([gumbel_uniform(7, c, r, a) for c in range(4) for r in range(200) for a in range(6)])
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+    assert len(np.unique(u)) > 0.99 * len(u)
+
+
+# ------------------------------------------------------------------------------------------------------ GPU parity
+def _run(nets, n_rows, segments, obs, rows_per_tile=128, **kw):
+    plan = PolicyPlan(nets, n_rows, segments, rows_per_tile=rows_per_tile)
+    dev = nets.device
+    out = dict(raw=torch.full((n_rows, 6), float("nan"), device=dev), actions=torch.full((n_rows,), -1, dtype=torch.int32, device=dev),
+               action_logp=torch.full((n_rows,), float("nan"), device=dev), logp=torch.full((n_rows, 6), float("nan"), device=dev))
+    plan.forward(obs, **out, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("digits", [4, 3])
+def test_kernel_matches_reference_actors_and_emulator(digits):
+    z, get = cases()
+    obs = torch.from_numpy(z["obs"]).cuda()                       # [240, 5, 4, 20]
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get(f"a{i}.") for i in range(3)], digits=digits)
+    order = [0, 1, 2, 2, 0, 1]                                    # six segments of 40 rows
+    raw = _run(nets, 240, [(40 * g, 40, k, 0) for g, k in enumerate(order)], obs)["raw"]
+    act = _run(nets, 240, [(40 * g, 40, k, TILE_ACT) for g, k in enumerate(order)], obs, deterministic=True)
+    tol = TOL if digits == 4 else 2 * TOL
+    for g, k in enumerate(order):
+        sl = slice(40 * g, 40 * g + 40)
+        assert np.abs(log_softmax(raw[sl]) - z[f"a{k}.logits"][sl]).max() < tol + TOL
+        assert np.abs(act["logp"][sl] - z[f"a{k}.logits"][sl]).max() < TOL_LOGP
+        assert np.array_equal(act["actions"][sl, None], z[f"a{k}.det_action"][sl])
+        assert np.abs(act["action_logp"][sl, None] - z[f"a{k}.det_logp"][sl]).max() < TOL_LOGP
+        # the emulator replays the same fmaf chains on the same packed image
+        emu = emulate_packed(pack_host(get(f"a{k}."), (5, 4, 20), ACTOR_HEAD, digits), z["obs"][sl].reshape(40, -1))
+        assert np.abs(raw[sl] - emu).max() < 2e-7
+    assert np.isnan(act["raw"]).all()                             # actor tiles do not write raw outputs
+
+
+@pytest.mark.gpu
+def test_kernel_critics_mixed_with_actors_one_launch():
+    z, get = cases()
+    obs = torch.from_numpy(z["obs"]).cuda()
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get("a0."), get("a1.")], critics=[get("c0."), get("c1.")])
+    assert nets.n_out == [6, 6, 1, 1]
+    segs = [(0, 100, 0, TILE_ACT), (100, 140, 1, TILE_ACT), (0, 60, 3, 0), (60, 180, 2, 0)]
+    plan = PolicyPlan(nets, 240, segs, rows_per_tile=64)
+    values = torch.zeros(240, device="cuda")
+    actions = torch.zeros(240, dtype=torch.int32, device="cuda")
+    alp = torch.zeros(240, device="cuda")
+    plan.forward(obs, raw=values, actions=actions, action_logp=alp, deterministic=True)
+    v = values.cpu().numpy()
+    assert np.abs(v[:60, None] - z["c1.values"][:60]).max() < TOL and np.abs(v[60:, None] - z["c0.values"][60:]).max() < TOL
+    a = actions.cpu().numpy()
+    assert np.array_equal(a[:100, None], z["a0.det_action"][:100]) and np.array_equal(a[100:, None], z["a1.det_action"][100:])
+
+
+@pytest.mark.gpu
+def test_kernel_second_grid_and_large_rows():
+    """unident_s: 9x5 grid, 21 conv positions, 900-byte rows (115 KB of LDS per workgroup: the opt-in size)."""
+    z, get = cases("policy_cases_unident_s.npz")
+    obs = torch.from_numpy(z["obs"]).cuda()
+    nets = PackedNetworks.from_state_dicts((9, 5, 20), "cuda", actors=[get("a0.")], critics=[get("c0.")])
+    r = _run(nets, 96, [(0, 96, 0, TILE_ACT)], obs, deterministic=True)
+    assert np.abs(r["logp"] - z["a0.logits"]).max() < TOL_LOGP
+    v = _run(nets, 96, [(0, 96, 1, 0)], obs)["raw"].reshape(-1)[:96 * 1]
+    # raw of a 1-output network is written with stride n_out = 1
+    assert np.abs(v[:96, None] - z["c0.values"]).max() < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(5, 5), (8, 5), (4, 3), (3, 3), (14, 9)])
+def test_kernel_other_grids_vs_oracle(W, H):
+    """Grids of the other shipped layouts (random0/1 5x5, random3 8x5, corridor 14x9 -- one wavefront per workgroup)
+    and the smallest ones, random weights, real-valued int8 inputs in the observation range; ragged row counts."""
+    rng = np.random.default_rng(W * 100 + H)
+    n = 203
+    obs_np = (rng.random((n, W, H, 20)) < 0.15).astype(np.int8) * rng.integers(1, 21, size=(n, W, H, 20), dtype=np.int8)
+    actor, critic = random_net(W, H, 6, ACTOR_HEAD, 1), random_net(W, H, 1, CRITIC_HEAD, 2)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[actor], critics=[critic])
+    obs = torch.from_numpy(obs_np).cuda()
+    want = reference_forward(actor, obs_np, ACTOR_HEAD)
+    scale = max(1.0, np.abs(want).max())
+    raw = _run(nets, n, [(0, 101, 0, 0), (101, 102, 0, 0)], obs, rows_per_tile=64)["raw"]
+    assert np.abs(raw - want).max() < 4e-6 * scale
+    v = torch.full((n,), float("nan"), device="cuda")
+    PolicyPlan(nets, n, [(3, 197, 1, 0)], rows_per_tile=32).forward(obs, raw=v)
+    v = v.cpu().numpy()
+    wantv = reference_forward(critic, obs_np, CRITIC_HEAD)[:, 0]
+    assert np.isnan(v[:3]).all() and np.isnan(v[200:]).all()
+    assert np.abs(v[3:200] - wantv[3:200]).max() < 4e-6 * max(1.0, np.abs(wantv).max())
+
+
+@pytest.mark.gpu
+def test_device_packer_equals_host_packer():
+    for (W, H, n_out, head) in [(5, 4, 6, ACTOR_HEAD), (9, 5, 1, CRITIC_HEAD)]:
+        sd = random_net(W, H, n_out, head, 11)
+        for digits in (1, 4):
+            nets = PackedNetworks((W, H, 20), 2, "cuda", digits=digits)
+            nets.pack(1, sd, head)
+            torch.cuda.synchronize()
+            assert np.array_equal(nets.image[1].cpu().numpy(), pack_host(sd, (W, H, 20), head, digits))
+            assert not nets.image[0].any()
+
+
+@pytest.mark.gpu
+def test_sampling_is_gumbel_max_of_the_exported_uniforms():
+    z, get = cases()
+    obs = torch.from_numpy(z["obs"]).cuda()
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get("a0.")])
+    r = _run(nets, 240, [(0, 240, 0, TILE_ACT)], obs, seed=1234, counter=9)
+    u = np.array([[gumbel_uniform(1234, 9, row, a) for a in range(6)] for row in range(240)], dtype=np.float32)
+    key = r["logp"] - np.log(-np.log(u))
+    top2 = np.sort(key, axis=-1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4                      # away from float ties the draw is reproducible
+    assert clear.sum() > 230 and np.array_equal(r["actions"][clear], key.argmax(-1)[clear])
+    assert np.allclose(r["action_logp"], np.take_along_axis(r["logp"], r["actions"][:, None].astype(np.int64), 1)[:, 0])
+    # different counters give different draws; the empirical law follows the probabilities
+    big = obs[:1].expand(20000, 5, 4, 20).contiguous()
+    rr = _run(nets, 20000, [(0, 20000, 0, TILE_ACT)], big, rows_per_tile=512, seed=5, counter=1)
+    freq = np.bincount(rr["actions"], minlength=6) / 20000
+    assert np.abs(freq - np.exp(z["a0.logits"][0])).max() < 0.015
+    r2 = _run(nets, 240, [(0, 240, 0, TILE_ACT)], obs, seed=1234, counter=10)
+    assert (r2["actions"] != r["actions"]).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_bad_tiles_are_clamped_not_faulting():
+    z, get = cases()
+    obs = torch.from_numpy(z["obs"]).cuda()
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get("a0.")])
+    plan = PolicyPlan(nets, 240, [(0, 240, 0, 0)], rows_per_tile=128)
+    plan.tiles = torch.tensor([[200, 500, 7, 0], [-5, 10, 0, 0], [100000, 32, 0, 0], [0, 64, -3, 0]], dtype=torch.int32, device="cuda")
+    plan.n_tiles = 4
+    raw = torch.full((250, 6), float("nan"), device="cuda")      # 10 canary rows behind the 240 real ones
+    plan.forward(obs, raw=raw[:240])
+    torch.cuda.synchronize()
+    raw = raw.cpu().numpy()
+    assert np.isnan(raw[240:]).all() and np.isnan(raw[64:200]).all()
+    want = reference_forward(get("a0."), z["obs"], ACTOR_HEAD)
+    assert np.abs(raw[200:240] - want[200:240]).max() < TOL and np.abs(raw[:64] - want[:64]).max() < TOL
