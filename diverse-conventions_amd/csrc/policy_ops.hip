@@ -35,7 +35,7 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load at 4-byte alignment
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 constexpr int kMaxOut = 8;
@@ -54,8 +54,12 @@ struct PolicyArgs {
     float *logp;                        // [n_rows][n_out] or NULL
     uint32_t seed, counter;
     int sample;                         // 0: argmax, 1: Gumbel-max draw
-    int lds_wave_bytes;
+    int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
+    int lds_wave_bytes;                 // one wavefront's row-staging area
 };
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
@@ -65,25 +69,72 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NDIG>
+// Copy 32 rows (one flat, contiguous block of the observation tensor) into this wavefront's staging area with
+// LDS-DMA loads: no VGPRs, so the copy for the NEXT block can be in flight under the dense layers of this one.
+// Pieces past the end of the tensor are skipped (their rows are never stored); the one piece that straddles the
+// end goes dword by dword.
+__device__ __forceinline__ void stage_rows(const PolicyArgs &a, uint8_t *ldsw, long long brow, int lane) {
+    const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
+    const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
+    for (int it = 0; it * 64 < n16; ++it) {
+        const int i = it * 64 + lane;
+        const long long off = base + 16ll * i;
+        if (i < n16 && off + 16 <= obs_bytes) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.obs + off), (lptr_t)(ldsw + it * 1024), 16, 0, 0);
+        } else if (i < n16 && off < obs_bytes) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (off + 4 * q + 4 <= obs_bytes)
+                    reinterpret_cast<uint32_t *>(ldsw + 16 * i)[q] = *reinterpret_cast<const uint32_t *>(a.obs + off + 4 * q);
+        }
+    }
+}
+
+// B operands of the conv at one position: for each kernel column kx the 60 contiguous bytes of tiles
+// (x'+kx, y'..y'+2) plus 4 bytes that meet zero weights, as 2 x 16 bytes per lane half.
+__device__ __forceinline__ void read_bfrags(const uint8_t *rowp, int pos_off, int colstep, v4i (&bfr)[6]) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + pos_off + kx * colstep + 32 * s);
+            v4i b;
+            b.x = static_cast<int>(q[0]); b.y = static_cast<int>(q[1]);
+            b.z = static_cast<int>(q[2]); b.w = static_cast<int>(q[3]);
+            bfr[kx * 2 + s] = b;
+        }
+}
+
+template <int NDIG, bool FC1_LDS>
 __global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    uint8_t *ldsw = reinterpret_cast<uint8_t *>(lds_raw) + static_cast<size_t>(wave) * a.lds_wave_bytes;
+    uint8_t *ldsw = lds + a.lds_weight_bytes + static_cast<size_t>(wave) * a.lds_wave_bytes;
 
     const int4 tile = a.tiles[blockIdx.x];
-    long long row0 = tile.x;
+    const long long row0 = tile.x;
     int nrows = tile.y;
     const int net = min(max(tile.z, 0), a.n_nets - 1);
     const int flags = tile.w;
-    if (row0 < 0 || row0 >= a.n_rows) return;                         // a bad tile does nothing
+    if (row0 < 0 || row0 >= a.n_rows) return;                         // a bad tile does nothing (whole workgroup)
     if (row0 + nrows > a.n_rows) nrows = static_cast<int>(a.n_rows - row0);
 
     const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
     const int n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
     const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
 
+    // first block's rows: in flight while the weights are fetched
+    if (wave * kRowsPerBlock < nrows) stage_rows(a, ldsw, row0 + static_cast<long long>(wave) * kRowsPerBlock, lane);
+
+    // LDS-resident weights: the image from fc1 (or, when fc1 does not fit, from b1) to its end, verbatim
+    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(blob + wstart);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < a.lds_weight_bytes / 16; i += blockDim.x) dst[i] = src[i];
+    }
     // conv weight digits live in registers for the whole tile: [kx*2+s][digit] x 16 bytes per lane
     v4i wA[6][NDIG];
     {
@@ -99,40 +150,38 @@ __global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
     }
-    const float *w1 = reinterpret_cast<const float *>(blob + a.L.off_fc1);
-    const float *b1 = reinterpret_cast<const float *>(blob + a.L.off_b1);
-    const float *w2 = reinterpret_cast<const float *>(blob + a.L.off_fc2);
-    const float *b2 = reinterpret_cast<const float *>(blob + a.L.off_b2);
-    const float *wh = reinterpret_cast<const float *>(blob + a.L.off_head);
-    const float *bh = reinterpret_cast<const float *>(blob + a.L.off_bh);
+    const v4f *w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
+    const v4f *w1l = reinterpret_cast<const v4f *>(lds + (a.L.off_fc1 - wstart)) + lane;
+    const float *b1 = reinterpret_cast<const float *>(lds + (a.L.off_b1 - wstart)) + h * 16;
+    const v4f *w2 = reinterpret_cast<const v4f *>(lds + (a.L.off_fc2 - wstart)) + lane;
+    const float *b2 = reinterpret_cast<const float *>(lds + (a.L.off_b2 - wstart)) + h * 16;
+    const v4f *wh = reinterpret_cast<const v4f *>(lds + (a.L.off_head - wstart)) + lane;
+    const float *bh = reinterpret_cast<const float *>(lds + (a.L.off_bh - wstart)) + h * 4;
+    __syncthreads();                                                  // the only workgroup barrier: weights are in LDS
 
-    const long long obs_bytes = a.n_rows * RB;
-    const int n16 = 2 * RB;                                           // 16-byte pieces in 32 rows
+    const uint8_t *rowp = ldsw + col * RB + 16 * h;
+    const int colstep = H * OC_POLICY_C;
 
     for (int blk = wave; blk * kRowsPerBlock < nrows; blk += nwaves) {
         const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        // ---- stage 32 rows: one flat copy, the LDS image is the HBM block verbatim ----
-        wave_lds_sync();
-        {
-            const long long base = brow * RB;
-            for (int i = lane; i < n16; i += 64) {
-                long long off = base + 16ll * i;
-                off = off > obs_bytes - 16 ? obs_bytes - 16 : off;    // rows past the end: any valid bytes will do
-                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(a.obs + off);
-                reinterpret_cast<uint4 *>(ldsw)[i] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
         wave_lds_sync();
 
+        v4i bfr[6];
+        read_bfrags(rowp, 0, colstep, bfr);
         v16f h1[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[m][r] = 0.f;
 
-        const uint8_t *rowp = ldsw + col * RB + 16 * h;
         int xq = 0, yq = 0;                                           // conv position p = xq * PH + yq
         for (int p = 0; p < P; ++p) {
+            // fc1 operands of this position: issued now, consumed after the conv
+            v4f w1r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w1r[q] = FC1_LDS ? w1l[(p * 8 + q) * 64] : w1g[(p * 8 + q) * 64];
+            __builtin_amdgcn_sched_barrier(0);                        // keep the issue above the conv (hipcc sinks it to the use)
             // ---- conv at position p: X^T[o][row] for the 32 rows ----
             v16i acc[NDIG];
 #pragma unroll
@@ -140,19 +189,10 @@ __global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[d][r] = 0;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const uint8_t *slab = rowp + ((xq + kx) * H + yq) * OC_POLICY_C;
+            for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(slab + 32 * s);
-                    v4i b;
-                    b.x = static_cast<int>(q[0]); b.y = static_cast<int>(q[1]);
-                    b.z = static_cast<int>(q[2]); b.w = static_cast<int>(q[3]);
-#pragma unroll
-                    for (int d = 0; d < NDIG; ++d)
-                        acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[kx * 2 + s][d], b, acc[d], 0, 0, 0);
-                }
-            }
+                for (int d = 0; d < NDIG; ++d)
+                    acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[ks][d], bfr[ks], acc[d], 0, 0, 0);
             v16f x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -161,52 +201,65 @@ __global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
                 for (int d = 1; d < NDIG; ++d) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[d][r]));
                 x[r] = fmaxf(__builtin_fmaf(t, csc[r], cbi[r]), 0.f);
             }
-            // ---- fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row] ----
-            const float *w1p = w1 + static_cast<size_t>(p) * 2048 + lane;
+            // ---- fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row], step f = 2s + m ----
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
+            for (int f = 0; f < 8; ++f)
+                h1[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[f >> 2][f & 3], x[f >> 1], h1[f & 1], 0, 0, 0);
+            // next position's B operands: issued behind the first fc1 steps (so that nothing waits for them here),
+            // consumed by the next iteration's conv
+            if (p + 1 < P && ++yq == PH) { yq = 0; ++xq; }           // (the last position is simply read again)
+            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    h1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1p[(m * 16 + s) * 64], x[s], h1[m], 0, 0, 0);
-            if (++yq == PH) { yq = 0; ++xq; }
+            for (int f = 8; f < 32; ++f)
+                h1[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[f >> 2][f & 3], x[f >> 1], h1[f & 1], 0, 0, 0);
         }
+        // the staging area is free: start the copy of this wavefront's next block under the dense layers
+        wave_lds_sync();
+        if ((blk + nwaves) * kRowsPerBlock < nrows)
+            stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+
+        // ---- fc2: h2^T[n2][row] = relu(W2 h1 + b2), input half m, step f = 2s + m2 ----
+        v4f w2r[2][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w2r[0][q] = w2[q * 64];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[m][r] = fmaxf(h1[m][r] + b1[(m * 2 + h) * 16 + r], 0.f);
-
-        // ---- fc2 ----
+            for (int r = 0; r < 16; ++r) h1[m][r] = fmaxf(h1[m][r] + b1[m * 32 + r], 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w2r[1][q] = w2[(8 + q) * 64];
         v16f h2[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h2[m][r] = 0.f;
 #pragma unroll
+        for (int f = 0; f < 32; ++f)
+            h2[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][f >> 2][f & 3], h1[0][f >> 1], h2[f & 1], 0, 0, 0);
+        v4f whr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) whr[q] = wh[q * 64];
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+            h2[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][f >> 2][f & 3], h1[1][f >> 1], h2[f & 1], 0, 0, 0);
+#pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-                    h2[m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[((m2 * 2 + m) * 16 + s) * 64 + lane], h1[m][s], h2[m2], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[m][r] = fmaxf(h2[m][r] + b2[(m * 2 + h) * 16 + r], 0.f);
+            for (int r = 0; r < 16; ++r) h2[m][r] = fmaxf(h2[m][r] + b2[m * 32 + r], 0.f);
 
-        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3 ----
+        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
         v16f out;
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(m * 16 + s) * 64 + lane], h2[m][s], out, 0, 0, 0);
+        for (int f = 0; f < 32; ++f)
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[f >> 2][f & 3], h2[f >> 4][f & 15], out, 0, 0, 0);
 
         float l[kMaxOut];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float mine = out[r] + bh[h * 4 + r];
+            const float mine = out[r] + bh[r];
             const float other = __shfl_xor(mine, 32);
             l[r] = h ? other : mine;
             l[r + 4] = h ? mine : other;
@@ -358,16 +411,26 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
     a.seed = seed; a.counter = counter; a.sample = sample_mode;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
+    // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
+    // CU; otherwise fc1 (8 KB per conv position) stays in L2 and is prefetched into registers per position.
+    constexpr long long kLds = 160 * 1024;
+    const long long w_all = a.L.off_bh + 32 - a.L.off_fc1, w_small = a.L.off_bh + 32 - a.L.off_b1;
     int waves = 4;
-    while (waves > 1 && static_cast<long long>(waves) * a.lds_wave_bytes > 160 * 1024) waves >>= 1;
-    const size_t lds = static_cast<size_t>(waves) * a.lds_wave_bytes;
-    if (lds > 160 * 1024) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
+    bool fc1_lds = w_all + 4ll * a.lds_wave_bytes <= kLds;
+    a.lds_weight_bytes = static_cast<int>(fc1_lds ? w_all : w_small);
+    while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
+    const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
+    if (lds > static_cast<size_t>(kLds)) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
     void (*kernel)(const PolicyArgs) = nullptr;
-    switch (shape->digits) {
-        case 1: kernel = oc_policy_kernel<1>; break;
-        case 2: kernel = oc_policy_kernel<2>; break;
-        case 3: kernel = oc_policy_kernel<3>; break;
-        default: kernel = oc_policy_kernel<4>; break;
+    switch (shape->digits * 2 + (fc1_lds ? 1 : 0)) {
+        case 2: kernel = oc_policy_kernel<1, false>; break;
+        case 3: kernel = oc_policy_kernel<1, true>; break;
+        case 4: kernel = oc_policy_kernel<2, false>; break;
+        case 5: kernel = oc_policy_kernel<2, true>; break;
+        case 6: kernel = oc_policy_kernel<3, false>; break;
+        case 7: kernel = oc_policy_kernel<3, true>; break;
+        case 8: kernel = oc_policy_kernel<4, false>; break;
+        default: kernel = oc_policy_kernel<4, true>; break;
     }
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -46,11 +46,11 @@ OC_HD inline oc_policy_layout oc_policy_make_layout(int W, int H, int digits, in
     int64_t o = OC_POLICY_HEADER_BYTES;
     L.off_conv = o;    o += (int64_t)6 * digits * 64 * 16;         // [kx*2+s][digit][lane][16] int8
     L.off_conv_sb = o; o += 2 * 2 * 16 * 4;                        // scale[h][reg], bias[h][reg] f32
-    L.off_fc1 = o;     o += (int64_t)L.P * 2 * 16 * 64 * 4;        // [p][m][s][lane] f32
+    L.off_fc1 = o;     o += (int64_t)L.P * 8 * 64 * 4 * 4;         // [p][q][lane][4] f32, step f = 4q+j = 2s+m
     L.off_b1 = o;      o += 2 * 2 * 16 * 4;                        // [m][h][reg]
-    L.off_fc2 = o;     o += 2 * 2 * 16 * 64 * 4;                   // [m2][m][s][lane]
+    L.off_fc2 = o;     o += 2 * 8 * 64 * 4 * 4;                    // [m][q][lane][4], f = 2s+m2
     L.off_b2 = o;      o += 2 * 2 * 16 * 4;
-    L.off_head = o;    o += 2 * 16 * 64 * 4;                       // [m][s][lane]
+    L.off_head = o;    o += 8 * 64 * 4 * 4;                        // [q][lane][4], f = 16m+s
     L.off_bh = o;      o += 2 * 4 * 4;                             // [h][reg 0..3]
     L.total = (o + 255) / 256 * 256;
     return L;
@@ -127,9 +127,12 @@ OC_HD inline float oc_policy_pack_conv_sb(const oc_policy_layout &L, const oc_po
     const float m = oc_policy_conv_absmax(w.conv_w, o);
     return (float)((double)m / (double)oc_policy_qmax(L.digits));
 }
-// fc1, idx over [P][2 m][16 s][64 lane]
+// The dense layers' A operands are stored so that one lane reads four consecutive MFMA steps with one 16-byte
+// load: [.. ][q = f / 4][lane][f % 4], f the position of the MFMA in the kernel's issue order.
+// fc1, idx over [P][8 q][64 lane][4]: issue order f = 2 s + m (k-step s = 0..15, output half m)
 OC_HD inline float oc_policy_pack_fc1(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
-    const int lane = (int)(idx & 63), s = (int)((idx >> 6) & 15), m = (int)((idx >> 10) & 1), p = (int)(idx >> 11);
+    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63), p = (int)(idx >> 11);
+    const int s = f >> 1, m = f & 1;
     const int n = 32 * m + (lane & 31), o = oc_mfma_row(s, lane >> 5);
     return w.fc1_w[(int64_t)n * (OC_POLICY_O * L.P) + o * L.P + p];
 }
@@ -138,15 +141,16 @@ OC_HD inline float oc_policy_pack_hbias(const float *b, int64_t idx) {
     const int reg = (int)(idx & 15), h = (int)((idx >> 4) & 1), m = (int)(idx >> 5);
     return b[32 * m + oc_mfma_row(reg, h)];
 }
-// fc2, idx over [2 m2][2 m][16 s][64 lane]
+// fc2, idx over [2 m][8 q][64 lane][4]: input half m, issue order inside it f = 2 s + m2
 OC_HD inline float oc_policy_pack_fc2(const oc_policy_weights &w, int64_t idx) {
-    const int lane = (int)(idx & 63), s = (int)((idx >> 6) & 15), m = (int)((idx >> 10) & 1), m2 = (int)(idx >> 11);
+    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63), m = (int)(idx >> 11);
+    const int s = f >> 1, m2 = f & 1;
     return w.fc2_w[(32 * m2 + (lane & 31)) * OC_POLICY_HID + 32 * m + oc_mfma_row(s, lane >> 5)];
 }
-// head, idx over [2 m][16 s][64 lane]; rows >= n_out are zero
+// head, idx over [8 q][64 lane][4]: issue order f = 16 m + s; rows >= n_out are zero
 OC_HD inline float oc_policy_pack_head(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
-    const int lane = (int)(idx & 63), s = (int)((idx >> 6) & 15), m = (int)(idx >> 10);
-    const int a = lane & 31;
+    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63);
+    const int m = f >> 4, s = f & 15, a = lane & 31;
     return a < L.n_out ? w.head_w[a * OC_POLICY_HID + 32 * m + oc_mfma_row(s, lane >> 5)] : 0.f;
 }
 // head bias, idx over [2 h][4 reg]: output a = reg + 4 h

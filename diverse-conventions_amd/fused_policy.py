@@ -69,6 +69,8 @@ class PackedNetworks:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("PackedNetworks lives on the GPU (the fused policy kernel has no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.digits, self.n_nets = int(digits), int(n_nets)
         self.bytes_per_net = packed_bytes(self.W, self.H, self.digits)
         self.image = torch.zeros((self.n_nets, self.bytes_per_net), dtype=torch.uint8, device=self.device)
