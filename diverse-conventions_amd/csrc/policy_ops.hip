@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "overcooked_hip.h"
@@ -56,7 +57,13 @@ struct PolicyArgs {
     int sample;                         // 0: argmax, 1: Gumbel-max draw
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
     int lds_wave_bytes;                 // one wavefront's row-staging area
+    unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*4 + wave][16] stamps, or NULL
 };
+
+__device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, int slot) {
+    if (a.trace && lane == 0)
+        a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 16 + slot] = slot >= 14 ? clock64() : wall_clock64();
+}
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -76,6 +83,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void stage_rows(const PolicyArgs &a, uint8_t *ldsw, long long brow, int lane) {
     const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
     const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
+    if (base + 16ll * n16 <= obs_bytes) {                             // whole block inside the tensor (wave-uniform)
+        const int8_t *src = a.obs + base + 16 * lane;
+        int it = 0;
+        for (; (it + 1) * 64 <= n16; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsw + it * 1024), 16, 0, 0);
+        if (it * 64 + lane < n16)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsw + it * 1024), 16, 0, 0);
+        return;
+    }
     for (int it = 0; it * 64 < n16; ++it) {
         const int i = it * 64 + lane;
         const long long off = base + 16ll * i;
@@ -105,8 +121,8 @@ __device__ __forceinline__ void read_bfrags(const uint8_t *rowp, int pos_off, in
         }
 }
 
-template <int NDIG, bool FC1_LDS>
-__global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
+template <int NDIG, bool FC1_LDS, bool CONV_LDS>
+__global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -125,186 +141,262 @@ __global__ __launch_bounds__(256) void oc_policy_kernel(const PolicyArgs a) {
     const int n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
     const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
 
+    stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
     // first block's rows: in flight while the weights are fetched
     if (wave * kRowsPerBlock < nrows) stage_rows(a, ldsw, row0 + static_cast<long long>(wave) * kRowsPerBlock, lane);
 
-    // LDS-resident weights: the image from fc1 (or, when fc1 does not fit, from b1) to its end, verbatim
-    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);
+    // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the tail
+    // from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once (a
+    // load / wait / ds_write loop cost one L2 round trip per pass).
+    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);          // image offset of the tail
+    const int conv_bytes = CONV_LDS ? static_cast<int>(a.L.off_fc1 - a.L.off_conv) : 0;
+    uint8_t *lds_tail = lds + conv_bytes;                                             // LDS address of image offset wstart
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(blob + wstart);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        for (int i = threadIdx.x; i < a.lds_weight_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        const int n16c = conv_bytes / 16, n16 = n16c + (a.lds_weight_bytes - conv_bytes) / 16;
+        for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
+            const int i = i0 + lane;
+            if (i < n16) {
+                const uint8_t *src = i < n16c ? blob + a.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
+            }
+        }
     }
-    // conv weight digits live in registers for the whole tile: [kx*2+s][digit] x 16 bytes per lane
-    v4i wA[6][NDIG];
-    {
+    // conv weight digits: [kx*2+s][digit] x 16 bytes per lane, read from LDS per use or (when the LDS is needed for
+    // large rows) held in registers for the whole tile
+    v4i wA[CONV_LDS ? 1 : 6][NDIG];
+    const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
+    if (!CONV_LDS) {
         const v4i *src = reinterpret_cast<const v4i *>(blob + a.L.off_conv);
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks)
+        for (int ks = 0; ks < (CONV_LDS ? 1 : 6); ++ks)
 #pragma unroll
             for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
     }
-    float csc[16], cbi[16];
-    {
+    // conv scale / bias per accumulator register: registers when the conv section is not LDS-resident, otherwise
+    // read from LDS where they are used (32 registers the resident plan needs for its prefetch rings)
+    float csc[CONV_LDS ? 1 : 16], cbi[CONV_LDS ? 1 : 16];
+    const float *sbl = reinterpret_cast<const float *>(lds + (a.L.off_conv_sb - a.L.off_conv)) + h * 16;
+    if (!CONV_LDS) {
         const float *sb = reinterpret_cast<const float *>(blob + a.L.off_conv_sb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
     }
     const v4f *w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
-    const v4f *w1l = reinterpret_cast<const v4f *>(lds + (a.L.off_fc1 - wstart)) + lane;
-    const float *b1 = reinterpret_cast<const float *>(lds + (a.L.off_b1 - wstart)) + h * 16;
-    const v4f *w2 = reinterpret_cast<const v4f *>(lds + (a.L.off_fc2 - wstart)) + lane;
-    const float *b2 = reinterpret_cast<const float *>(lds + (a.L.off_b2 - wstart)) + h * 16;
-    const v4f *wh = reinterpret_cast<const v4f *>(lds + (a.L.off_head - wstart)) + lane;
-    const float *bh = reinterpret_cast<const float *>(lds + (a.L.off_bh - wstart)) + h * 4;
+    const v4f *w1l = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc1 - wstart)) + lane;
+    const float *b1 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b1 - wstart)) + h * 16;
+    const v4f *w2 = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
+    const float *b2 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b2 - wstart)) + h * 16;
+    const v4f *wh = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_head - wstart)) + lane;
+    const float *bh = reinterpret_cast<const float *>(lds_tail + (a.L.off_bh - wstart)) + h * 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wavefront's share of the weight copy has landed
     __syncthreads();                                                  // the only workgroup barrier: weights are in LDS
 
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     const int colstep = H * OC_POLICY_C;
+    stamp(a, wave, lane, 1);
 
-    for (int blk = wave; blk * kRowsPerBlock < nrows; blk += nwaves) {
-        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
-        wave_lds_sync();
-
-        v4i bfr[6];
-        read_bfrags(rowp, 0, colstep, bfr);
-        v16f h1[2];
+    // conv result -> fc1 operand: f32(sum of digit accumulators) * scale + bias, ReLU; one accumulator register
+    auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
+        float t = static_cast<float>(acc[0][r]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int d = 1; d < NDIG; ++d) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[d][r]));
+        return CONV_LDS ? fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f) : fmaxf(__builtin_fmaf(t, csc[0 + (CONV_LDS ? 0 : r)], cbi[0 + (CONV_LDS ? 0 : r)]), 0.f);
+    };
+    auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1[m][r] = 0.f;
-
-        int xq = 0, yq = 0;                                           // conv position p = xq * PH + yq
-        for (int p = 0; p < P; ++p) {
-            // fc1 operands of this position: issued now, consumed after the conv
-            v4f w1r[8];
+        for (int d = 0; d < NDIG; ++d)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) w1r[q] = FC1_LDS ? w1l[(p * 8 + q) * 64] : w1g[(p * 8 + q) * 64];
-            __builtin_amdgcn_sched_barrier(0);                        // keep the issue above the conv (hipcc sinks it to the use)
-            // ---- conv at position p: X^T[o][row] for the 32 rows ----
-            v16i acc[NDIG];
+            for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+        if (CONV_LDS) {
+            // weight digits stream through a three-deep register ring, two kernel-column steps ahead of their
+            // MFMAs; the group barriers pin that order (left alone, hipcc issues each read right before its
+            // use and waits out the LDS latency 6 x digits times per position)
+            constexpr int RD = NDIG == 4 ? 2 : 3;                     // ring depth the 256-register budget allows
+            v4i wq[RD][NDIG];
 #pragma unroll
-            for (int d = 0; d < NDIG; ++d)
+            for (int g = 0; g < RD - 1; ++g)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+                for (int d = 0; d < NDIG; ++d) wq[g][d] = wcl[(g * NDIG + d) * 64];
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                if (ks + RD - 1 < 6) {
+#pragma unroll
+                    for (int d = 0; d < NDIG; ++d) wq[(ks + RD - 1) % RD][d] = wcl[((ks + RD - 1) * NDIG + d) * 64];
+                }
+#pragma unroll
+                for (int d = 0; d < NDIG; ++d)
+                    acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[ks % RD][d], bfr[ks], acc[d], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, (RD - 1) * NDIG, 0);      // DS reads of the leading steps
+#pragma unroll
+            for (int ks = 0; ks + RD - 1 < 6; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NDIG, 0);             // reads of step ks + RD - 1
+                __builtin_amdgcn_sched_group_barrier(0x008, NDIG, 0);             // MFMAs of step ks
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, (RD - 1) * NDIG, 0);
+        } else {
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
                 for (int d = 0; d < NDIG; ++d)
-                    acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[ks][d], bfr[ks], acc[d], 0, 0, 0);
-            v16f x;
+                    acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[CONV_LDS ? 0 : ks][d], bfr[ks], acc[d], 0, 0, 0);
+        }
+    };
+
+    for (int blk = wave; blk * kRowsPerBlock < nrows; blk += nwaves) {
+        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
+        if (blk == wave) stamp(a, wave, lane, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
+        wave_lds_sync();
+        if (blk == wave) stamp(a, wave, lane, 3);
+
+        // The position loop is software-pipelined by hand: one wavefront per SIMD issues in order, so anything
+        // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
+        // p run, the VALU turns the conv accumulators of position p+1 into fc1 operands (needed one iteration
+        // later, so nothing waits for them), and the LDS reads for position p+2 are in flight.
+        int pi = 0, xq = 0, yq = 0;                                   // position whose B operands `bfr` holds
+        auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
+        v4i bfr[6];
+        read_bfrags(rowp, 0, colstep, bfr);
+        v16i acc[NDIG];
+        conv(acc, bfr);                                               // position 0
+        advance();
+        read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        v16f h1[2];                                                   // accumulators start at the bias
+        {
+            const v4f *bq = reinterpret_cast<const v4f *>(b1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = static_cast<float>(acc[0][r]);
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int d = 1; d < NDIG; ++d) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[d][r]));
-                x[r] = fmaxf(__builtin_fmaf(t, csc[r], cbi[r]), 0.f);
-            }
-            // ---- fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row], step f = 2s + m ----
+                for (int r = 0; r < 16; ++r) h1[m][r] = bq[m * 8 + (r >> 2)][r & 3];
+        }
+        v16f x;
 #pragma unroll
-            for (int f = 0; f < 8; ++f)
-                h1[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[f >> 2][f & 3], x[f >> 1], h1[f & 1], 0, 0, 0);
-            // next position's B operands: issued behind the first fc1 steps (so that nothing waits for them here),
-            // consumed by the next iteration's conv
-            if (p + 1 < P && ++yq == PH) { yq = 0; ++xq; }           // (the last position is simply read again)
-            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        for (int r = 0; r < 16; ++r) x[r] = combine(acc, r);
+
+        for (int p = 0; p < P; ++p) {
+            v4f w1r[8];                                               // fc1 operands of this position
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w1r[q] = FC1_LDS ? w1l[(p * 8 + q) * 64] : w1g[(p * 8 + q) * 64];
+            __builtin_amdgcn_sched_barrier(0);                        // keep the issue up here (hipcc sinks it to the use)
+            if (p + 1 < P) conv(acc, bfr);                            // conv of position p+1
             __builtin_amdgcn_sched_barrier(0);
+            advance();
+            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
+            __builtin_amdgcn_sched_barrier(0);
+            // fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row], step f = 2s + m
 #pragma unroll
-            for (int f = 8; f < 32; ++f)
-                h1[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[f >> 2][f & 3], x[f >> 1], h1[f & 1], 0, 0, 0);
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx) & 3], x[sidx], h1[0], 0, 0, 0);
+                h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx + 1) & 3], x[sidx], h1[1], 0, 0, 0);
+                x[sidx] = combine(acc, sidx);                         // next position's operand, once this one is consumed
+            }
+        }
+        if (blk == wave) stamp(a, wave, lane, 4);
+        // dense-layer operands: all issued here, consumed below
+        v4f w2r[2][8], whr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { w2r[0][q] = w2[q * 64]; w2r[1][q] = w2[(8 + q) * 64]; }
+        v16f h2[2], out;
+        {
+            const v4f *bq = reinterpret_cast<const v4f *>(b2);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h2[m][r] = bq[m * 8 + (r >> 2)][r & 3];
+            const v4f bhv = *reinterpret_cast<const v4f *>(bh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[r] = r < 4 ? bhv[r] : 0.f;
         }
         // the staging area is free: start the copy of this wavefront's next block under the dense layers
         wave_lds_sync();
         if ((blk + nwaves) * kRowsPerBlock < nrows)
             stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- fc2: h2^T[n2][row] = relu(W2 h1 + b2), input half m, step f = 2s + m2 ----
-        v4f w2r[2][8];
+        // ---- fc2: h2^T[n2][row] = relu(b2 + W2 relu(h1)), input half m, step f = 2s + m2 ----
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w2r[0][q] = w2[q * 64];
+        for (int r = 0; r < 16; ++r) h1[0][r] = fmaxf(h1[0][r], 0.f);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h1[m][r] = fmaxf(h1[m][r] + b1[m * 32 + r], 0.f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) w2r[1][q] = w2[(8 + q) * 64];
-        v16f h2[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[m][r] = 0.f;
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-            h2[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][f >> 2][f & 3], h1[0][f >> 1], h2[f & 1], 0, 0, 0);
-        v4f whr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) whr[q] = wh[q * 64];
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-            h2[f & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][f >> 2][f & 3], h1[1][f >> 1], h2[f & 1], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[m][r] = fmaxf(h2[m][r] + b2[m * 32 + r], 0.f);
-
-        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
-        v16f out;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = 0.f;
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[f >> 2][f & 3], h2[f >> 4][f & 15], out, 0, 0, 0);
-
-        float l[kMaxOut];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mine = out[r] + bh[r];
-            const float other = __shfl_xor(mine, 32);
-            l[r] = h ? other : mine;
-            l[r + 4] = h ? mine : other;
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx) & 3], h1[0][sidx], h2[0], 0, 0, 0);
+            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx + 1) & 3], h1[0][sidx], h2[1], 0, 0, 0);
+            h1[1][sidx] = fmaxf(h1[1][sidx], 0.f);                    // in the shadow: needed by the second half
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) whr[q] = wh[q * 64];             // head operands: in flight under the second half
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx) & 3], h1[1][sidx], h2[0], 0, 0, 0);
+            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx + 1) & 3], h1[1][sidx], h2[1], 0, 0, 0);
+        }
+        if (blk == wave) stamp(a, wave, lane, 5);
+        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[0][r] = fmaxf(h2[0][r], 0.f);
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[sidx >> 2][sidx & 3], h2[0][sidx], out, 0, 0, 0);
+            h2[1][sidx] = fmaxf(h2[1][sidx], 0.f);
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx)
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[4 + (sidx >> 2)][sidx & 3], h2[1][sidx], out, 0, 0, 0);
+        if (blk == wave) stamp(a, wave, lane, 6);
+
+        // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
+        //      work on their own actions and meet through three lane exchanges ----
         const long long row = brow + col;
-        const bool valid = h == 0 && (blk * kRowsPerBlock + col) < nrows;
+        const bool valid = (blk * kRowsPerBlock + col) < nrows;
         if (!(flags & OC_POLICY_TILE_ACT)) {
             if (valid && a.raw) {
 #pragma unroll
-                for (int i = 0; i < kMaxOut; ++i)
-                    if (i < n_out) a.raw[row * n_out + i] = l[i];
+                for (int r = 0; r < 4; ++r)
+                    if (4 * h + r < n_out) a.raw[row * n_out + 4 * h + r] = out[r];
             }
             continue;
         }
-        // ---- actor epilogue: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80),
-        //      then argmax (mode) or a Gumbel-max draw ----
-        float mx = l[0];
+        // actor: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80), then argmax (mode) or
+        // a Gumbel-max draw
+        float mx = -INFINITY;
 #pragma unroll
-        for (int i = 1; i < kMaxOut; ++i)
-            if (i < n_out) mx = fmaxf(mx, l[i]);
+        for (int r = 0; r < 4; ++r)
+            if (4 * h + r < n_out) mx = fmaxf(mx, out[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxOut; ++i)
-            if (i < n_out) sum += expf(l[i] - mx);
+        for (int r = 0; r < 4; ++r)
+            if (4 * h + r < n_out) sum += expf(out[r] - mx);
+        sum += __shfl_xor(sum, 32);
         const float lse = mx + logf(sum);
         int best = 0;
         float best_key = -INFINITY, best_lp = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxOut; ++i) {
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * h + r;
             if (i < n_out) {
-                const float lp = l[i] - lse;
+                const float lp = out[r] - lse;
                 float key = lp;
-                if (a.sample) {
+                if (a.sample) {                                       // the noise needs no more than the fast logarithm
                     const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, a.counter, static_cast<uint32_t>(row), i));
-                    key = lp - logf(-logf(u));
+                    key = lp - __logf(-__logf(u));
                 }
                 if (key > best_key) { best_key = key; best = i; best_lp = lp; }
                 if (valid && a.logp) a.logp[row * n_out + i] = lp;
             }
         }
-        if (valid) {
+        {
+            const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
+            const int obest = __shfl_xor(best, 32);
+            if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
+        }
+        if (valid && h == 0) {
             if (a.actions) a.actions[row] = best;
             if (a.action_logp) a.action_logp[row] = best_lp;
         }
+        if (blk == wave) stamp(a, wave, lane, 7);
     }
+    stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
 __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
@@ -313,6 +405,8 @@ __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, u
          i += static_cast<long long>(gridDim.x) * blockDim.x)
         dst[i] = oc_policy_pack_word(L, w, i);
 }
+
+unsigned long long *g_trace = nullptr;    // device buffer of the diagnostics entry below
 
 int check_shape(const oc_policy_shape *s, const char *who) {
     if (!s) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: shape is NULL", who);
@@ -410,28 +504,39 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
     a.seed = seed; a.counter = counter; a.sample = sample_mode;
+    a.trace = (g_trace && n_tiles <= 2048) ? g_trace : nullptr;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
     // CU; otherwise fc1 (8 KB per conv position) stays in L2 and is prefetched into registers per position.
     constexpr long long kLds = 160 * 1024;
-    const long long w_all = a.L.off_bh + 32 - a.L.off_fc1, w_small = a.L.off_bh + 32 - a.L.off_b1;
-    int waves = 4;
-    bool fc1_lds = w_all + 4ll * a.lds_wave_bytes <= kLds;
-    a.lds_weight_bytes = static_cast<int>(fc1_lds ? w_all : w_small);
+    const long long w_tail_all = a.L.off_bh + 32 - a.L.off_fc1, w_tail_small = a.L.off_bh + 32 - a.L.off_b1;
+    const long long w_conv = a.L.off_fc1 - a.L.off_conv, obs1 = a.lds_wave_bytes;
+    // Plan, in order of preference (the kernel fits 256 registers, so two wavefronts per SIMD can hide each
+    // other's LDS / VALU phases behind MFMAs):
+    //   8 wavefronts, conv digits + small tail resident, fc1 (8 KB per position) prefetched from L2 per position;
+    //   4 wavefronts with everything resident; 4 with fc1 from L2; then fewer wavefronts for very large rows.
+    int waves = 8;
+    bool fc1_lds = false, conv_lds = true;
+    if (w_conv + w_tail_small + 8 * obs1 > kLds) {
+        waves = 4;
+        if (w_conv + w_tail_all + 4 * obs1 <= kLds) fc1_lds = true;
+        else if (w_conv + w_tail_small + 4 * obs1 > kLds) conv_lds = false;
+    }
+    if (const char *env = getenv("OC_POLICY_PLAN")) {                 // diagnostics: "waves,fc1_lds,conv_lds"
+        int w = 0, f = 0, c = 0;
+        if (sscanf(env, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
+    }
+    a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
     const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
     if (lds > static_cast<size_t>(kLds)) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
-    void (*kernel)(const PolicyArgs) = nullptr;
-    switch (shape->digits * 2 + (fc1_lds ? 1 : 0)) {
-        case 2: kernel = oc_policy_kernel<1, false>; break;
-        case 3: kernel = oc_policy_kernel<1, true>; break;
-        case 4: kernel = oc_policy_kernel<2, false>; break;
-        case 5: kernel = oc_policy_kernel<2, true>; break;
-        case 6: kernel = oc_policy_kernel<3, false>; break;
-        case 7: kernel = oc_policy_kernel<3, true>; break;
-        case 8: kernel = oc_policy_kernel<4, false>; break;
-        default: kernel = oc_policy_kernel<4, true>; break;
-    }
+    typedef void (*kernel_t)(const PolicyArgs);
+    static const kernel_t kernels[4][2][2] = {
+        {{oc_policy_kernel<1, false, false>, oc_policy_kernel<1, false, true>}, {oc_policy_kernel<1, true, false>, oc_policy_kernel<1, true, true>}},
+        {{oc_policy_kernel<2, false, false>, oc_policy_kernel<2, false, true>}, {oc_policy_kernel<2, true, false>, oc_policy_kernel<2, true, true>}},
+        {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
+        {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
+    const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -440,6 +545,22 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
+    return OC_OK;
+}
+
+/* Diagnostics, deliberately not in the public header: per-wavefront phase stamps of the following launches
+ * (tools/trace_policy.py).  enable: allocate and zero; otherwise copy [n_waves][16] stamps out and free. */
+int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves) {
+    const size_t cap = 4096 * 4 * 16 * sizeof(unsigned long long);
+    if (enable) {
+        if (!g_trace && hipMalloc(reinterpret_cast<void **>(&g_trace), cap) != hipSuccess) return OC_ERR_HIP;
+        return hipMemset(g_trace, 0, cap) == hipSuccess ? OC_OK : OC_ERR_HIP;
+    }
+    if (!g_trace) return OC_OK;
+    (void)hipDeviceSynchronize();
+    if (host_out) (void)hipMemcpy(host_out, g_trace, static_cast<size_t>(n_waves < 4096 * 4 ? n_waves : 4096 * 4) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(g_trace);
+    g_trace = nullptr;
     return OC_OK;
 }
 

@@ -71,8 +71,10 @@ def build(force=False, verbose=False):
                 'static const char oc_step_kernel_src[] = R"OCKSRC(' + text + ')OCKSRC";\n')
     # -ffp-contract=off: rollout_ops.hip must round like the reference's separate torch ops (no FMA); the
     # engine itself has no floating point
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", INCLUDE,
-           "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
+    # -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs (policy_ops.hip reads them with VALU ops; the
+    # accumulator-file form cost 64 v_accvgpr_read per conv position and kept the kernel at one wavefront per SIMD)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-fPIC", "-shared", "-I", INCLUDE, "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -51,7 +51,7 @@ def test_oracle_matches_reference_outputs():
     assert np.abs(reference_forward(get("c0."), z["obs"], CRITIC_HEAD) - z["c0.values"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("digits,tol", [(4, 1e-6), (3, 3e-6), (2, 3e-4)])
+@pytest.mark.parametrize("digits,tol", [(4, 2e-6), (3, 3e-6), (2, 3e-4)])
 def test_packed_image_emulation_matches_reference(digits, tol):
     """Host packer + lane-level emulation of the kernel's MFMA dataflow == reference outputs (no GPU involved)."""
     z, get = cases()

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-wavefront phase timeline of ONE oc_policy_forward launch (s_memrealtime stamps, 100 MHz, of each wave's
+FIRST 32-row block; plus the shader clock over the wave's whole life).  Diagnostic only."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from diverse_conventions_amd import native
+from diverse_conventions_amd.fused_policy import ACTOR_HEAD, TILE_ACT, PackedNetworks, PolicyPlan
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_fused_policy import random_net
+
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 4)
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 245760
+rpt = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+digits = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+gen = torch.Generator().manual_seed(0)
+nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_net(W, H, 6, ACTOR_HEAD, gen) for _ in range(4)], digits=digits)
+obs = (torch.rand((rows, W, H, 20), device="cuda") < 0.1).to(torch.int8)
+seg = rows // 4
+plan = PolicyPlan(nets, rows, [(g * seg, seg, g, TILE_ACT) for g in range(4)], rows_per_tile=rpt)
+actions = torch.zeros(rows, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    plan.forward(obs, actions=actions)
+torch.cuda.synchronize()
+L = native.lib()
+L.oc_policy_debug_trace.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+assert L.oc_policy_debug_trace(1, None, 0) == 0
+plan.forward(obs, actions=actions)
+nw = plan.n_tiles * 8
+buf = np.zeros((nw, 16), dtype=np.uint64)
+assert L.oc_policy_debug_trace(0, buf.ctypes.data_as(ctypes.c_void_p), nw) == 0
+buf = buf[buf[:, 0] > 0]
+t = buf[:, :9].astype(np.float64) / 100.0
+t0 = t[:, 0].min()
+names = ["start", "weights+regs in (barrier passed)", "block 0: before row wait", "rows landed", "conv+fc1 done", "fc2 done",
+         "head done", "epilogue done (block 0)", "wave end"]
+print(f"{W}x{H} rows={rows} rows_per_tile={rpt} digits={digits}: {plan.n_tiles} tiles, {len(buf)} waves")
+for i, nm in enumerate(names):
+    c = t[:, i] - t0
+    print(f"  {nm:34s} min {c.min():7.2f}  median {np.median(c):7.2f}  max {c.max():7.2f} us")
+d = t[:, 1:9] - t[:, 0:8]
+print("  phase durations (median us):", " ".join(f"{np.median(d[:, i]):.2f}" for i in range(8)))
+life_us = t[:, 8] - t[:, 0]
+cyc = (buf[:, 15] - buf[:, 14]).astype(np.float64)
+print(f"  shader clock over wave life: median {np.median(cyc / life_us):.0f} MHz; blocks per wave {rpt // 128}; "
+      f"median cycles per block after the first {np.median((t[:, 8] - t[:, 7]) * np.median(cyc / life_us) / max(1, rpt // 128 - 1)):.0f}")
