@@ -54,6 +54,7 @@ struct PolicyArgs {
     float *action_logp;                 // [n_rows]
     float *logp;                        // [n_rows][n_out] or NULL
     uint32_t seed, counter;
+    const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
     int sample;                         // 0: argmax, 1: Gumbel-max draw
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
     int lds_wave_bytes;                 // one wavefront's row-staging area
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
     const int n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
     const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
+    const uint32_t counter = a.counter + (a.counter_ptr ? *a.counter_ptr : 0u);
 
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
     // first block's rows: in flight while the weights are fetched
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 const float lp = out[r] - lse;
                 float key = lp;
                 if (a.sample) {                                       // the noise needs no more than the fast logarithm
-                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, a.counter, static_cast<uint32_t>(row), i));
+                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, counter, static_cast<uint32_t>(row), i));
                     key = lp - __logf(-__logf(u));
                 }
                 if (key > best_key) { best_key = key; best = i; best_lp = lp; }
@@ -484,7 +486,7 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
 
 int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, void *stream) {
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter, void *stream) {
     if (int rc = check_shape(shape, "oc_policy_forward")) return rc;
     if (!d_packed || !d_obs || !d_tiles || n_nets < 1 || n_rows < 1 || n_tiles < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
@@ -503,7 +505,7 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     if (n_rows * a.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
-    a.seed = seed; a.counter = counter; a.sample = sample_mode;
+    a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
     a.trace = (g_trace && n_tiles <= 2048) ? g_trace : nullptr;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a

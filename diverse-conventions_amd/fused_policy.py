@@ -141,7 +141,8 @@ class PolicyPlan:
         self.n_tiles = int(self.tiles.shape[0])
         self.counter = 0
 
-    def forward(self, obs, raw=None, actions=None, action_logp=None, logp=None, deterministic=False, seed=0, counter=None):
+    def forward(self, obs, raw=None, actions=None, action_logp=None, logp=None, deterministic=False, seed=0, counter=None,
+                device_counter=None):
         """obs: contiguous int8 tensor whose leading axes flatten to n_rows rows of W*H*20 bytes."""
         nets = self.nets
         rb = nets.W * nets.H * 20
@@ -151,13 +152,17 @@ class PolicyPlan:
                             ("action_logp", action_logp, torch.float32), ("logp", logp, torch.float32)):
             if t is not None and (t.dtype != dt or not t.is_contiguous() or t.device != nets.device):
                 raise ValueError(f"{name} must be a contiguous {dt} tensor on {nets.device}")
+        if device_counter is not None:
+            if device_counter.dtype != torch.int32 or device_counter.device != nets.device or device_counter.numel() != 1:
+                raise ValueError("device_counter must be a one-element int32 tensor on the networks' device")
+            counter = 0 if counter is None else counter
         if counter is None:
             counter, self.counter = self.counter, self.counter + 1
         shape = _shape(nets.W, nets.H, 6, nets.digits)
         native.check(native.lib().oc_policy_forward(ctypes.byref(shape), _ptr(nets.image), nets.n_nets, _ptr(obs), self.n_rows,
                                                     _ptr(self.tiles), self.n_tiles, _ptr(raw), _ptr(actions), _ptr(action_logp),
                                                     _ptr(logp), 0 if deterministic else 1, int(seed) & 0xFFFFFFFF,
-                                                    int(counter) & 0xFFFFFFFF, _stream(nets.device)))
+                                                    int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(nets.device)))
 
 
 def gumbel_uniform(seed, counter, row, action):

@@ -60,3 +60,81 @@ class PairedRollout:
         with torch.cuda.graph(self.graph):
             self._step()
         return self
+
+
+class FusedPairedRollout:
+    """PairedRollout with every policy of the step on the fused MFMA kernel (`oc_policy_forward`): ONE policy launch
+    -- all conventions' actors, optionally their critics, both sides, every pairing segment -- plus ONE env launch
+    per step, instead of the reference's 2(2k+1) `get_actions` calls (train/XD/xd_player.py:190-207,
+    train/partner_agents.py:97-111).  The kernel reads the engine's int8 observations and writes the int32 actions
+    `oc_step` reads; log-probabilities and values land in `[2, N]` float buffers (or a trajectory slot).
+
+    actor_nets[side][g] / critic_nets[side][g]: network index in `nets` playing / valuing segment g on that side
+    (defaults: actors from `pairing_segments`; no critics)."""
+
+    def __init__(self, engine: OvercookedEngine, nets, threads: int, n_conventions: int, actor_nets=None, critic_nets=None,
+                 ego_id: int = 0, deterministic: bool = False, seed: int = 0, rows_per_tile=None):
+        from .fused_policy import TILE_ACT, PolicyPlan
+        self.engine, self.nets, self.threads = engine, nets, threads
+        self.segments = pairing_segments(threads, n_conventions)
+        g, n = len(self.segments), engine.num_kitchens
+        if n != g * threads:
+            raise ValueError(f"engine must hold threads*(2k+1) = {g * threads} kitchens")
+        if actor_nets is None:
+            actor_nets = [None, None]
+            actor_nets[ego_id] = segment_policy_indices(self.segments, "ego")
+            actor_nets[1 - ego_id] = segment_policy_indices(self.segments, "partner")
+        rows = []
+        for side in range(2):
+            for s in range(g):
+                rows.append((side * n + s * threads, threads, actor_nets[side][s], TILE_ACT))
+                if critic_nets is not None:
+                    rows.append((side * n + s * threads, threads, critic_nets[side][s], 0))
+        self.plan = PolicyPlan(nets, 2 * n, rows, rows_per_tile=rows_per_tile)
+        dev = engine.device
+        self.deterministic, self.seed = deterministic, seed
+        self.actions = torch.zeros((2, n), dtype=torch.int32, device=dev)
+        self.logp = torch.zeros((2, n), dtype=torch.float32, device=dev)
+        self.values = torch.zeros((2, n), dtype=torch.float32, device=dev) if critic_nets is not None else None
+        self.draw = torch.zeros(1, dtype=torch.int32, device=dev)        # device-side draw counter: graph replays differ
+        self.graph = None
+
+    def _policies(self, obs, actions, logp, values):
+        self.plan.forward(obs, raw=values, actions=actions, action_logp=logp, deterministic=self.deterministic,
+                          seed=self.seed, counter=0, device_counter=self.draw)
+        self.draw.add_(1)
+
+    def _step(self):
+        self._policies(self.engine.obs, self.actions, self.logp, self.values)
+        self.engine.step(self.actions)
+
+    def step(self):
+        """One env step for all segments -> (obs, reward, done) engine buffers (overwritten next step)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step()
+        return self.engine.obs, self.engine.reward, self.engine.done
+
+    def capture(self, warmup: int = 3):
+        s = torch.cuda.Stream(self.engine.device)
+        s.wait_stream(torch.cuda.current_stream(self.engine.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream(self.engine.device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        return self
+
+    def collect(self, traj, logp=None, values=None):
+        """Fill a TrajectoryBuffer: step t reads `traj.obs[t]`, writes actions straight into `traj.actions[t]` and the
+        env step writes `traj.obs[t+1]`, `traj.reward[t]`, `traj.done[t]` -- two launches per step, no copies.
+        logp / values: optional float32 [T, 2, N] destinations."""
+        traj.start()
+        for t in range(traj.T):
+            self._policies(traj.obs[t], traj.actions[t], None if logp is None else logp[t], None if values is None else values[t])
+            self.engine.step(traj.actions[t], obs=traj.obs[t + 1], reward=traj.reward[t], done=traj.done[t])
+        traj.t = traj.T
+        return traj

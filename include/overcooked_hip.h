@@ -236,11 +236,12 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
  * d_obs int8 [n_rows][W][H][20], d_tiles int32 [n_tiles][4] on the device.  Tiles without OC_POLICY_TILE_ACT write
  * d_raw[row * n_out + a] (raw head outputs: critic values, or logits); tiles with it write d_actions[row] (int32),
  * d_action_logp[row] and, if non-NULL, d_logp[row * n_out + a] (normalised log-probabilities).  sample_mode 0 =
- * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter, row, a).
+ * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter + *d_counter, row, a);
+ * d_counter (device uint32, may be NULL = 0) lets a captured HIP graph draw fresh actions on every replay.
  * Rows and network indices of a bad tile are clamped; any output pointer may be NULL. */
 int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, void *stream);
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter, void *stream);
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
 
 /* Introspection */

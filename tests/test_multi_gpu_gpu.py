@@ -152,3 +152,89 @@ def test_paired_rollout_eager_and_graph(layout_params):
         runs.append(eng.obs.cpu().numpy().copy())
         eng.close()
     assert np.array_equal(runs[0], runs[1])
+
+
+def _golden_nets():
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
+    pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}
+    return [pick(f"a{i}.") for i in range(3)], [pick(f"c{i}.") for i in range(2)]
+
+
+def test_fused_paired_rollout_eager_graph_and_reference_policies(layout_params):
+    """f2 on the MFMA kernel: one policy launch + one env launch per step.  Deterministic actors, so the fused
+    rollout, its HIP-graph replay, the batched-GEMM PyTorch path and an oracle env driven by the same actions
+    must agree exactly; critic values against the reference-architecture PyTorch evaluation within 2e-6."""
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks
+    from diverse_conventions_amd.policy import StackedActors, StackedCritics
+    actors_sd, critics_sd = _golden_nets()
+    params = layout_params["simple"]
+    threads, k, T = 64, 2, 40
+    n = threads * (2 * k + 1)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=actors_sd, critics=critics_sd)
+    sa, sc = StackedActors(actors_sd, (5, 4, 20), "cuda"), StackedCritics(critics_sd, (5, 4, 20), "cuda")
+    critic_of = [[3, 4, 3, 4, 3], [4, 4, 3, 3, 4]]                   # arbitrary critic per (side, segment); nets 3, 4
+    runs = []
+    for use_graph in (False, True):
+        eng = OvercookedEngine(params, n, 0)
+        ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=critic_of, deterministic=True, rows_per_tile=32)
+        if use_graph:
+            ro.capture()
+            eng.reset_all()
+        ora = oracle.OracleVecEnv(params, n)
+        for t in range(T):
+            prev = eng.obs.clone()
+            obs, rew, done = ro.step()
+            acts = ro.actions.cpu().numpy()
+            for p in range(2):
+                for g, seg in enumerate(ro.segments):
+                    pol = seg.ego_policy if p == 0 else seg.partner_policy
+                    o = prev[p, seg.start:seg.stop].unsqueeze(0)
+                    a, lp = sa.act(o, torch.tensor([pol]), deterministic=True)
+                    assert np.array_equal(a.view(-1).cpu().numpy(), acts[p, seg.start:seg.stop]), (t, p, g)
+                    assert (lp.view(-1) - ro.logp[p, seg.start:seg.stop]).abs().max() < 4e-6
+                    v = sc.values(o, torch.tensor([critic_of[p][g] - 3]))
+                    assert (v.view(-1) - ro.values[p, seg.start:seg.stop]).abs().max() < 2e-6
+            oobs, orew, odone = ora.step(acts)
+            assert np.array_equal(obs.cpu().numpy(), oobs) and np.array_equal(rew.cpu().numpy(), orew), t
+        runs.append(eng.obs.cpu().numpy().copy())
+        eng.close()
+    assert np.array_equal(runs[0], runs[1])
+
+
+def test_fused_rollout_collects_a_trajectory_in_place(layout_params):
+    """collect(): policies read trajectory slot t and write actions into the trajectory, the env step writes slot
+    t+1 -- the recorded actions replayed through the oracle reproduce every recorded observation/reward/done, the
+    recorded log-probs are those of the recorded actions, and sampled graph replays differ from step to step."""
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer
+    from diverse_conventions_amd.policy import StackedActors
+    actors_sd, critics_sd = _golden_nets()
+    params = layout_params["simple"]
+    threads, k, T = 96, 1, 30
+    n = threads * (2 * k + 1)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=actors_sd[:2], critics=critics_sd[:1])
+    eng = OvercookedEngine(params, n, 0)
+    ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=[[2] * 3, [2] * 3], seed=11)
+    traj = TrajectoryBuffer(eng, T)
+    logp = torch.zeros((T, 2, n), device="cuda")
+    values = torch.zeros((T, 2, n), device="cuda")
+    ro.collect(traj, logp=logp, values=values)
+    ora = oracle.OracleVecEnv(params, n)
+    assert np.array_equal(traj.obs[0].cpu().numpy(), ora.encode())
+    acts = traj.actions.cpu().numpy()
+    for t in range(T):
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(traj.obs[t + 1].cpu().numpy(), oobs) and np.array_equal(traj.reward[t].cpu().numpy(), orew)
+        assert np.array_equal(traj.done[t].cpu().numpy(), odone)
+    sa = StackedActors(actors_sd[:2], (5, 4, 20), "cuda")
+    for p in range(2):
+        for g, seg in enumerate(ro.segments):
+            pol = seg.ego_policy if p == 0 else seg.partner_policy
+            o = traj.obs[:T, p, seg.start:seg.stop].reshape(1, T * threads, 5, 4, 20)
+            lp_all = sa.log_probs(o, torch.tensor([pol])).view(T, threads, 6)
+            a = traj.actions[:, p, seg.start:seg.stop].long()
+            assert (lp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1) - logp[:, p, seg.start:seg.stop]).abs().max() < 4e-6
+    assert len(np.unique(acts)) == 6 and (acts[1:] != acts[:-1]).mean() > 0.3          # really sampled, step to step
+    assert int(ro.draw.item()) == T
+    eng.close()
