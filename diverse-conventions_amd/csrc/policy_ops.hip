@@ -55,6 +55,7 @@ struct PolicyArgs {
     float *logp;                        // [n_rows][n_out] or NULL
     uint32_t seed, counter;
     const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
+    const int32_t *row_select;          // [n_rows] or NULL: tiles with a select code only write rows whose entry matches
     int sample;                         // 0: argmax, 1: Gumbel-max draw
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
     int lds_wave_bytes;                 // one wavefront's row-staging area
@@ -349,7 +350,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
         //      work on their own actions and meet through three lane exchanges ----
         const long long row = brow + col;
-        const bool valid = (blk * kRowsPerBlock + col) < nrows;
+        bool valid = (blk * kRowsPerBlock + col) < nrows;
+        const int sel = (flags >> 8) & 0xff;                          // OC_POLICY_TILE_SELECT(v): only rows with row_select == v
+        if (sel && a.row_select && valid) valid = a.row_select[row] == sel - 1;
         if (!(flags & OC_POLICY_TILE_ACT)) {
             if (valid && a.raw) {
 #pragma unroll
@@ -486,7 +489,8 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
 
 int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter, void *stream) {
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                      const int32_t *d_row_select, void *stream) {
     if (int rc = check_shape(shape, "oc_policy_forward")) return rc;
     if (!d_packed || !d_obs || !d_tiles || n_nets < 1 || n_rows < 1 || n_tiles < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
@@ -505,7 +509,7 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     if (n_rows * a.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
-    a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
+    a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.row_select = d_row_select; a.sample = sample_mode;
     a.trace = (g_trace && n_tiles <= 2048) ? g_trace : nullptr;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a

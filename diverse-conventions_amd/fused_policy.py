@@ -20,6 +20,11 @@ ACTOR_HEAD = "act.action_out.linear"        # reference utils/act.py + distribut
 CRITIC_HEAD = "v_out"                       # reference r_actor_critic.py:165
 TILE_ACT = 1                                # OC_POLICY_TILE_ACT
 
+
+def tile_select(v):
+    """OC_POLICY_TILE_SELECT(v): the tile writes only rows whose `row_select` entry equals v."""
+    return ((int(v) + 1) & 0xFF) << 8
+
 _KEYS = ("base.cnn.cnn.0.weight", "base.cnn.cnn.0.bias", "base.cnn.cnn.3.weight", "base.cnn.cnn.3.bias",
          "base.cnn.cnn.5.weight", "base.cnn.cnn.5.bias")
 
@@ -142,7 +147,7 @@ class PolicyPlan:
         self.counter = 0
 
     def forward(self, obs, raw=None, actions=None, action_logp=None, logp=None, deterministic=False, seed=0, counter=None,
-                device_counter=None):
+                device_counter=None, row_select=None):
         """obs: contiguous int8 tensor whose leading axes flatten to n_rows rows of W*H*20 bytes."""
         nets = self.nets
         rb = nets.W * nets.H * 20
@@ -156,13 +161,16 @@ class PolicyPlan:
             if device_counter.dtype != torch.int32 or device_counter.device != nets.device or device_counter.numel() != 1:
                 raise ValueError("device_counter must be a one-element int32 tensor on the networks' device")
             counter = 0 if counter is None else counter
+        if row_select is not None and (row_select.dtype != torch.int32 or not row_select.is_contiguous() or row_select.device != nets.device
+                                       or row_select.numel() != self.n_rows):
+            raise ValueError(f"row_select must be a contiguous int32 tensor of {self.n_rows} entries on {nets.device}")
         if counter is None:
             counter, self.counter = self.counter, self.counter + 1
         shape = _shape(nets.W, nets.H, 6, nets.digits)
         native.check(native.lib().oc_policy_forward(ctypes.byref(shape), _ptr(nets.image), nets.n_nets, _ptr(obs), self.n_rows,
                                                     _ptr(self.tiles), self.n_tiles, _ptr(raw), _ptr(actions), _ptr(action_logp),
                                                     _ptr(logp), 0 if deterministic else 1, int(seed) & 0xFFFFFFFF,
-                                                    int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(nets.device)))
+                                                    int(counter) & 0xFFFFFFFF, _ptr(device_counter), _ptr(row_select), _stream(nets.device)))
 
 
 def gumbel_uniform(seed, counter, row, action):

@@ -214,6 +214,7 @@ typedef struct {
 } oc_policy_shape;
 
 #define OC_POLICY_TILE_ACT 1   /* tile flag: actor epilogue (log-softmax, action draw); otherwise raw head outputs */
+#define OC_POLICY_TILE_SELECT(v) ((((v) + 1) & 0xff) << 8)   /* tile flag: write only rows whose d_row_select entry == v (0..254) */
 
 /* Bytes of one packed network (a function of width, height, digits only; multiple of 256). < 0 on error. */
 int64_t oc_policy_packed_bytes(const oc_policy_shape *shape);
@@ -238,10 +239,14 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
  * d_action_logp[row] and, if non-NULL, d_logp[row * n_out + a] (normalised log-probabilities).  sample_mode 0 =
  * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter + *d_counter, row, a);
  * d_counter (device uint32, may be NULL = 0) lets a captured HIP graph draw fresh actions on every replay.
+ * d_row_select (int32 [n_rows], may be NULL): per-row policy mixing -- tiles flagged OC_POLICY_TILE_SELECT(v) write only
+ * the rows whose entry equals v, so two networks laid over the same rows fill one output buffer between them (the
+ * reference's `mix_mask == i` indexing, train/XD/xd_player.py:287-305, train/partner_agents.py:171-196).
  * Rows and network indices of a bad tile are clamped; any output pointer may be NULL. */
 int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter, void *stream);
+                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                      const int32_t *d_row_select, void *stream);
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
 
 /* Introspection */

@@ -100,7 +100,7 @@ def test_abi_argument_checks_and_tile_plan():
     assert L.oc_policy_packed_bytes(ctypes.byref(S(2, 4, 64, 6, 4))) < 0
     assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 64, 9, 4))) < 0
     assert L.oc_policy_packed_bytes(ctypes.byref(S(5, 4, 64, 6, 5))) < 0
-    assert L.oc_policy_forward(ctypes.byref(S(5, 4, 64, 6, 4)), None, 1, None, 10, None, 1, None, None, None, None, 0, 0, 0, None, None) == -1
+    assert L.oc_policy_forward(ctypes.byref(S(5, 4, 64, 6, 4)), None, 1, None, 10, None, 1, None, None, None, None, 0, 0, 0, None, None, None) == -1
     t = plan_tiles([(0, 300, 2, TILE_ACT), (300, 64, 5, 0), (364, 0, 1, 0)], 128).numpy()
     assert t.tolist() == [[0, 128, 2, 1], [128, 128, 2, 1], [256, 44, 2, 1], [300, 64, 5, 0]]
     with pytest.raises(native.OvercookedNativeError):
