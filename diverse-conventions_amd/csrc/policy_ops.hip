@@ -21,7 +21,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +51,8 @@ struct PolicyArgs {
     long long n_rows;
     int RB;                             // bytes per row = W*H*20
     const int4 *tiles;                  // {row0, nrows, net, flags}
+    int n_tiles;
+    int tile_per_wg;                    // 1: workgroup i owns tile i; 0: the table's blocks are split evenly over the grid
     float *raw;                         // [n_rows][n_out] raw head outputs (tiles without OC_POLICY_TILE_ACT)
     int32_t *actions;                   // [n_rows]
     float *action_logp;                 // [n_rows]
@@ -131,72 +135,82 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const int col = lane & 31, h = lane >> 5;
     uint8_t *ldsw = lds + a.lds_weight_bytes + static_cast<size_t>(wave) * a.lds_wave_bytes;
 
-    const int4 tile = a.tiles[blockIdx.x];
-    const long long row0 = tile.x;
-    int nrows = tile.y;
-    const int net = min(max(tile.z, 0), a.n_nets - 1);
-    const int flags = tile.w;
-    if (row0 < 0 || row0 >= a.n_rows) return;                         // a bad tile does nothing (whole workgroup)
-    if (row0 + nrows > a.n_rows) nrows = static_cast<int>(a.n_rows - row0);
+    // ---- work distribution.  The tile table lists (row range, network, flags); its 32-row blocks, in table order,
+    // are split EVENLY over the workgroups of the launch (one per CU), so a workgroup owns a contiguous stretch of
+    // blocks that may run through several tiles.  Weights are (re)loaded only when the network changes along the
+    // stretch.  Everything here is wave-uniform (scalar loads of the table).
+    auto tile_blocks = [&](const int4 t) -> int {
+        long long nr = t.y;
+        if (t.x < 0 || t.x >= a.n_rows || nr <= 0) return 0;          // a bad tile contributes nothing
+        if (t.x + nr > a.n_rows) nr = a.n_rows - t.x;
+        return static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
+    };
+    // Every wavefront scans the table itself, 64 entries per pass (one coalesced load + a wave prefix sum; a scalar
+    // loop costs one dependent L2 round trip per entry), first for the total, then for the entry holding its first block.
+    auto scan64 = [&](int base_tile, int &nb, int &incl) {
+        const int i = base_tile + lane;
+        int4 t = make_int4(0, 0, 0, 0);
+        if (i < a.n_tiles) t = a.tiles[i];
+        nb = i < a.n_tiles ? tile_blocks(t) : 0;
+        incl = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+    };
+    long long total = 0;
+    if (!a.tile_per_wg)
+    for (int c = 0; c < a.n_tiles; c += 64) {
+        int nb, incl;
+        scan64(c, nb, incl);
+        total += __builtin_amdgcn_readlane(incl, 63);
+    }
+    // (a planned table -- about one balanced tile per CU, oc_policy_plan_tiles -- maps tile i to workgroup i instead)
+    const long long wg0 = a.tile_per_wg ? 0 : total * blockIdx.x / gridDim.x;
+    const long long wg1 = a.tile_per_wg ? tile_blocks(a.tiles[blockIdx.x]) : total * (blockIdx.x + 1) / gridDim.x;
+    if (wg0 >= wg1) return;
+    int ti = a.tile_per_wg ? static_cast<int>(blockIdx.x) : 0;
+    long long tstart = 0;                                             // first block of tile ti
+    if (!a.tile_per_wg)
+    for (int c = 0; c < a.n_tiles; c += 64) {
+        int nb, incl;
+        scan64(c, nb, incl);
+        const long long target = wg0 - tstart;
+        const unsigned long long hit = __ballot(static_cast<long long>(incl - nb) <= target && target < incl);
+        if (hit) {
+            const int src = __ffsll(static_cast<long long>(hit)) - 1;
+            ti = c + src;
+            tstart += __builtin_amdgcn_readfirstlane(__shfl(incl - nb, src));
+            break;
+        }
+        tstart += __builtin_amdgcn_readlane(incl, 63);
+    }
+    ti = __builtin_amdgcn_readfirstlane(ti);
 
-    const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
-    const int n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
     const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
     const uint32_t counter = a.counter + (a.counter_ptr ? *a.counter_ptr : 0u);
-
-    stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
-    // first block's rows: in flight while the weights are fetched
-    if (wave * kRowsPerBlock < nrows) stage_rows(a, ldsw, row0 + static_cast<long long>(wave) * kRowsPerBlock, lane);
-
-    // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the tail
-    // from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once (a
-    // load / wait / ds_write loop cost one L2 round trip per pass).
-    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);          // image offset of the tail
+    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);          // image offset of the LDS tail
     const int conv_bytes = CONV_LDS ? static_cast<int>(a.L.off_fc1 - a.L.off_conv) : 0;
     uint8_t *lds_tail = lds + conv_bytes;                                             // LDS address of image offset wstart
-    {
-        const int n16c = conv_bytes / 16, n16 = n16c + (a.lds_weight_bytes - conv_bytes) / 16;
-        for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
-            const int i = i0 + lane;
-            if (i < n16) {
-                const uint8_t *src = i < n16c ? blob + a.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
-            }
-        }
-    }
     // conv weight digits: [kx*2+s][digit] x 16 bytes per lane, read from LDS per use or (when the LDS is needed for
-    // large rows) held in registers for the whole tile
+    // large rows) held in registers; conv scale / bias per accumulator register likewise
     v4i wA[CONV_LDS ? 1 : 6][NDIG];
-    const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
-    if (!CONV_LDS) {
-        const v4i *src = reinterpret_cast<const v4i *>(blob + a.L.off_conv);
-#pragma unroll
-        for (int ks = 0; ks < (CONV_LDS ? 1 : 6); ++ks)
-#pragma unroll
-            for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
-    }
-    // conv scale / bias per accumulator register: registers when the conv section is not LDS-resident, otherwise
-    // read from LDS where they are used (32 registers the resident plan needs for its prefetch rings)
     float csc[CONV_LDS ? 1 : 16], cbi[CONV_LDS ? 1 : 16];
+    const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
     const float *sbl = reinterpret_cast<const float *>(lds + (a.L.off_conv_sb - a.L.off_conv)) + h * 16;
-    if (!CONV_LDS) {
-        const float *sb = reinterpret_cast<const float *>(blob + a.L.off_conv_sb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
-    }
-    const v4f *w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
+    const v4f *w1g = nullptr;
     const v4f *w1l = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc1 - wstart)) + lane;
     const float *b1 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b1 - wstart)) + h * 16;
     const v4f *w2 = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
     const float *b2 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b2 - wstart)) + h * 16;
     const v4f *wh = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_head - wstart)) + lane;
     const float *bh = reinterpret_cast<const float *>(lds_tail + (a.L.off_bh - wstart)) + h * 4;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wavefront's share of the weight copy has landed
-    __syncthreads();                                                  // the only workgroup barrier: weights are in LDS
-
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     const int colstep = H * OC_POLICY_C;
-    stamp(a, wave, lane, 1);
+    int loaded_net = -1, n_out = 1;
+    bool trace_done = false;
+    stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     // conv result -> fc1 operand: f32(sum of digit accumulators) * scale + bias, ReLU; one accumulator register
     auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
@@ -246,12 +260,63 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         }
     };
 
-    for (int blk = wave; blk * kRowsPerBlock < nrows; blk += nwaves) {
+  for (long long cur = wg0; cur < wg1;) {
+    const int4 tile = a.tiles[ti];
+    const int tnb = tile_blocks(tile);
+    if (tnb == 0) { ++ti; continue; }
+    const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
+    const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);   // this stretch of the tile
+    const long long row0 = tile.x;
+    const int nrows = static_cast<int>(row0 + tile.y > a.n_rows ? a.n_rows - row0 : tile.y);
+    const int net = min(max(tile.z, 0), a.n_nets - 1);
+    const int flags = tile.w;
+    cur = run_end;
+    if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
+
+    // this wavefront's first block of the stretch: in flight while (if) the weights are fetched
+    if (first + wave < last) stage_rows(a, ldsw, row0 + static_cast<long long>(first + wave) * kRowsPerBlock, lane);
+    if (net != loaded_net) {
+        __syncthreads();                                              // everybody is done with the previous network
+        const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
+        n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
+        // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the
+        // tail from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once
+        // (a load / wait / ds_write loop cost one L2 round trip per pass).
+        {
+            const int n16c = conv_bytes / 16, n16 = n16c + (a.lds_weight_bytes - conv_bytes) / 16;
+            for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
+                const int i = i0 + lane;
+                if (i < n16) {
+                    const uint8_t *src = i < n16c ? blob + a.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
+                }
+            }
+        }
+        if (!CONV_LDS) {
+            const v4i *src = reinterpret_cast<const v4i *>(blob + a.L.off_conv);
+#pragma unroll
+            for (int ks = 0; ks < (CONV_LDS ? 1 : 6); ++ks)
+#pragma unroll
+                for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
+            const float *sb = reinterpret_cast<const float *>(blob + a.L.off_conv_sb);
+#pragma unroll
+            for (int r = 0; r < (CONV_LDS ? 1 : 16); ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
+        }
+        w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's share of the weight copy has landed
+        __syncthreads();                                              // the network is in LDS
+        loaded_net = net;
+        stamp(a, wave, lane, 1);
+    }
+
+    for (int blk = first + wave; blk < last; blk += nwaves) {
         const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        if (blk == wave) stamp(a, wave, lane, 2);
+        const bool traced = a.trace != nullptr && !trace_done;       // diagnostics: this wavefront's first block of the launch
+        trace_done = true;
+        if (traced) stamp(a, wave, lane, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
         wave_lds_sync();
-        if (blk == wave) stamp(a, wave, lane, 3);
+        if (traced) stamp(a, wave, lane, 3);
 
         // The position loop is software-pipelined by hand: one wavefront per SIMD issues in order, so anything
         // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
@@ -295,7 +360,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 x[sidx] = combine(acc, sidx);                         // next position's operand, once this one is consumed
             }
         }
-        if (blk == wave) stamp(a, wave, lane, 4);
+        if (traced) stamp(a, wave, lane, 4);
         // dense-layer operands: all issued here, consumed below
         v4f w2r[2][8], whr[8];
 #pragma unroll
@@ -313,7 +378,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         }
         // the staging area is free: start the copy of this wavefront's next block under the dense layers
         wave_lds_sync();
-        if ((blk + nwaves) * kRowsPerBlock < nrows)
+        if (blk + nwaves < last)
             stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
         __builtin_amdgcn_sched_barrier(0);
 
@@ -333,7 +398,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx) & 3], h1[1][sidx], h2[0], 0, 0, 0);
             h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx + 1) & 3], h1[1][sidx], h2[1], 0, 0, 0);
         }
-        if (blk == wave) stamp(a, wave, lane, 5);
+        if (traced) stamp(a, wave, lane, 5);
         // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2[0][r] = fmaxf(h2[0][r], 0.f);
@@ -345,7 +410,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
 #pragma unroll
         for (int sidx = 0; sidx < 16; ++sidx)
             out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[4 + (sidx >> 2)][sidx & 3], h2[1][sidx], out, 0, 0, 0);
-        if (blk == wave) stamp(a, wave, lane, 6);
+        if (traced) stamp(a, wave, lane, 6);
 
         // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
         //      work on their own actions and meet through three lane exchanges ----
@@ -371,9 +436,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) sum += expf(out[r] - mx);
+            if (4 * h + r < n_out) sum += __expf(out[r] - mx);      // v_exp_f32: relative error ~1e-7 on arguments <= 0
         sum += __shfl_xor(sum, 32);
-        const float lse = mx + logf(sum);
+        const float lse = mx + __logf(sum);                          // sum in [1, n_out]: absolute error ~2e-7
         int best = 0;
         float best_key = -INFINITY, best_lp = 0.f;
 #pragma unroll
@@ -399,8 +464,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             if (a.actions) a.actions[row] = best;
             if (a.action_logp) a.action_logp[row] = best_lp;
         }
-        if (blk == wave) stamp(a, wave, lane, 7);
+        if (traced) stamp(a, wave, lane, 7);
     }
+  }
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
@@ -468,18 +534,52 @@ int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const fl
 
 int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
                              int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity) {
-    if (!seg_row0 || !seg_rows || !seg_net || n_segs < 0 || rows_per_tile < kRowsPerBlock || rows_per_tile % kRowsPerBlock)
-        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: bad arguments (rows_per_tile must be a multiple of %d)", kRowsPerBlock);
-    int64_t n = 0;
+    const bool balanced = rows_per_tile < 0;                          // -rows_per_tile = number of workgroups to fill
+    if (!seg_row0 || !seg_rows || !seg_net || n_segs < 0 || rows_per_tile == 0 ||
+        (!balanced && (rows_per_tile < kRowsPerBlock || rows_per_tile % kRowsPerBlock)))
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: bad arguments (rows_per_tile: a multiple of %d, or -workgroups)", kRowsPerBlock);
+    std::vector<int64_t> blocks(n_segs), pieces(n_segs);
+    int64_t total = 0;
     for (int32_t g = 0; g < n_segs; ++g) {
         if (seg_row0[g] < 0 || seg_rows[g] < 0 || seg_row0[g] + seg_rows[g] > INT32_MAX)
             return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: segment %d out of range", g);
-        for (int64_t r = 0; r < seg_rows[g]; r += rows_per_tile, ++n) {
+        blocks[g] = (seg_rows[g] + kRowsPerBlock - 1) / kRowsPerBlock;
+        total += blocks[g];
+    }
+    if (balanced) {
+        // One tile = one workgroup = one network, so no workgroup reloads weights.  Pieces per segment in proportion
+        // to its 32-row blocks, then the spare workgroups go, one at a time, to the segment with the largest pieces.
+        const int64_t wgs = -static_cast<int64_t>(rows_per_tile);
+        int64_t used = 0;
+        for (int32_t g = 0; g < n_segs; ++g) {
+            pieces[g] = blocks[g] == 0 ? 0 : std::max<int64_t>(1, std::min(blocks[g], total ? wgs * blocks[g] / total : 1));
+            used += pieces[g];
+        }
+        for (; used < wgs; ++used) {
+            int32_t best = -1;
+            double worst = 1.0;                                       // only segments whose pieces exceed one block
+            for (int32_t g = 0; g < n_segs; ++g)
+                if (pieces[g] > 0 && pieces[g] < blocks[g] && static_cast<double>(blocks[g]) / pieces[g] > worst) {
+                    worst = static_cast<double>(blocks[g]) / pieces[g];
+                    best = g;
+                }
+            if (best < 0) break;
+            ++pieces[best];
+        }
+    } else {
+        for (int32_t g = 0; g < n_segs; ++g) pieces[g] = (seg_rows[g] + rows_per_tile - 1) / rows_per_tile;
+    }
+    int64_t n = 0;
+    for (int32_t g = 0; g < n_segs; ++g) {
+        int64_t done_blocks = 0;
+        for (int64_t i = 0; i < pieces[g]; ++i, ++n) {
+            const int64_t nb = balanced ? blocks[g] / pieces[g] + (i < blocks[g] % pieces[g] ? 1 : 0) : rows_per_tile / kRowsPerBlock;
+            const int64_t r = done_blocks * kRowsPerBlock, left = seg_rows[g] - r;
+            done_blocks += nb;
             if (!host_tiles) continue;
             if (n >= capacity) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: capacity %lld too small", (long long)capacity);
-            const int64_t left = seg_rows[g] - r;
             host_tiles[4 * n + 0] = static_cast<int32_t>(seg_row0[g] + r);
-            host_tiles[4 * n + 1] = static_cast<int32_t>(left < rows_per_tile ? left : rows_per_tile);
+            host_tiles[4 * n + 1] = static_cast<int32_t>(std::min(left, nb * kRowsPerBlock));
             host_tiles[4 * n + 2] = seg_net[g];
             host_tiles[4 * n + 3] = seg_flags ? seg_flags[g] : 0;
         }
@@ -508,9 +608,10 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     a.RB = shape->width * shape->height * OC_POLICY_C;
     if (n_rows * a.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
+    a.n_tiles = n_tiles;
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
     a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.row_select = d_row_select; a.sample = sample_mode;
-    a.trace = (g_trace && n_tiles <= 2048) ? g_trace : nullptr;
+    a.trace = g_trace;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
     // CU; otherwise fc1 (8 KB per conv position) stays in L2 and is prefetched into registers per position.
@@ -548,7 +649,20 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
+    // one workgroup per CU; each takes an equal share of the 32-row blocks (workgroups without a share return at once)
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+            return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot query the CU count");
+        n_cus = v;
+    }
+    // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
+    // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
+    a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
+    int grid = a.tile_per_wg ? n_tiles : n_cus;
+    if (const char *env = getenv("OC_POLICY_GRID")) { const int g = atoi(env); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
     return OC_OK;

@@ -136,11 +136,8 @@ class PolicyPlan:
             if row0 < 0 or rows < 0 or row0 + rows > self.n_rows or not 0 <= net < nets.n_nets:
                 raise ValueError(f"segment ({row0}, {rows}, net {net}) outside {self.n_rows} rows / {nets.n_nets} networks")
         if rows_per_tile is None:
-            # about two workgroups per CU, each long enough to amortise its weight loads
-            total = sum(s[1] for s in segments)
-            cus = torch.cuda.get_device_properties(nets.device).multi_processor_count
-            want = -(-total // (2 * cus))
-            rows_per_tile = max(128, min(2048, -(-want // 128) * 128))
+            # balanced plan: one tile per CU, pieces of one segment (= one network) each
+            rows_per_tile = -torch.cuda.get_device_properties(nets.device).multi_processor_count
         self.rows_per_tile = int(rows_per_tile)
         self.tiles = plan_tiles(segments, self.rows_per_tile).to(nets.device)
         self.n_tiles = int(self.tiles.shape[0])

@@ -228,9 +228,13 @@ int oc_policy_pack_host(const oc_policy_shape *shape, const float *conv_w, const
 int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const float *d_conv_b, const float *d_fc1_w,
                    const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b, const float *d_head_w,
                    const float *d_head_b, void *d_dst, void *stream);
-/* Cut segments (row0, rows, network index, flags) into workgroup tiles of at most rows_per_tile rows (multiple of
- * 32): host_tiles int32 [capacity][4] = {row0, rows, net, flags}.  Returns the tile count (host_tiles may be NULL
- * to ask for it), < 0 on error.  Pairing segments: train/XD/serial.py:27, xd_player.py:76-77,94. */
+/* Cut segments (row0, rows, network index, flags) into workgroup tiles: host_tiles int32 [capacity][4] = {row0, rows,
+ * net, flags}.  rows_per_tile > 0 (a multiple of 32): fixed-size tiles.  rows_per_tile < 0: -rows_per_tile workgroups
+ * (pass the CU count) are shared out over the segments in proportion to their rows and every segment is cut into
+ * near-equal pieces -- one balanced tile per CU, no workgroup ever changes network.  Returns the tile count
+ * (host_tiles may be NULL to ask for it), < 0 on error.  oc_policy_forward runs a table of >= CUs/2 tiles one
+ * workgroup per tile, a shorter one by splitting its 32-row blocks evenly over one workgroup per CU.
+ * Pairing segments: train/XD/serial.py:27, xd_player.py:76-77,94. */
 int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
                              int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity);
 /* d_packed: n_nets packed networks of this shape (n_out may differ per network; it is read from each image),

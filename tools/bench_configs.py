@@ -86,7 +86,50 @@ def config3(n=8192, k=7, T=400):
     return out
 
 
+def config3_policies(n=8192, k=7, T=200, critics=True):
+    """Config 3 with the policies in the loop: per layout 8 conventions' actors (+ one critic per segment and side) on
+    the fused MFMA kernel + the env step, five layouts on five streams (the HBM-bound env kernel of one layout overlaps
+    the MFMA-bound policy kernel of another)."""
+    from diverse_conventions_amd import FusedPairedRollout, PackedNetworks
+    threads = n // (2 * k + 1)
+    G = 2 * k + 1
+    gen = torch.Generator().manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, generator=gen) * 0.1
+    rollouts, streams = [], []
+    for name in CLASSIC_LAYOUTS:
+        params = get_base_layout_params(name, 200)
+        W, H = params["width"], params["height"]
+        P = (W - 2) * (H - 2)
+        trunk = lambda: {"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+                         "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64)}
+        actors = [dict(trunk(), **{"act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)}) for _ in range(k + 1)]
+        crit = [dict(trunk(), **{"v_out.weight": r(1, 64), "v_out.bias": r(1)}) for _ in range(G)] if critics else []
+        nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=crit)
+        eng = OvercookedEngine(params, threads * G, 0)
+        rollouts.append(FusedPairedRollout(eng, nets, threads, k, critic_nets=[[k + 1 + g for g in range(G)]] * 2 if critics else None))
+        streams.append(torch.cuda.Stream())
+
+    def run():
+        for ro, st in zip(rollouts, streams):
+            with torch.cuda.stream(st):
+                for _ in range(T):
+                    ro.step()
+    run()
+    sec = timed(run)
+    kitchens = sum(ro.engine.num_kitchens for ro in rollouts)
+    out = {"what": "config 3 with policies in the loop: 5 classic layouts x 8190 kitchens, 8 conventions in 15 pairing segments, "
+                   "fused MFMA policy kernel (actors" + (" + critics" if critics else "") + ") + env step, 5 streams",
+           "kitchens_total": kitchens, "us_per_joint_step": round(sec * 1e6 / T, 1), "agent_env_steps_per_s": round(2 * kitchens * T / sec)}
+    for ro in rollouts:
+        ro.engine.close()
+    return out
+
+
 if __name__ == "__main__":
+    if "--policies" in sys.argv:
+        print(json.dumps(config3_policies(critics=False)), flush=True)
+        print(json.dumps(config3_policies(critics=True)), flush=True)
+        sys.exit(0)
     for r in (single("cramped_room", 65536), time_major("cramped_room", 65536), single("cramped_room", 4096),
               single("asymmetric_advantages", 8192), single("asymmetric_advantages", 65536),
               single("coordination_ring", 65536), single("counter_circuit", 65536), config3()):

@@ -27,7 +27,7 @@ L = native.lib()
 L.oc_policy_debug_trace.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
 assert L.oc_policy_debug_trace(1, None, 0) == 0
 plan.forward(obs, actions=actions)
-nw = plan.n_tiles * 8
+nw = 256 * 8
 buf = np.zeros((nw, 16), dtype=np.uint64)
 assert L.oc_policy_debug_trace(0, buf.ctypes.data_as(ctypes.c_void_p), nw) == 0
 buf = buf[buf[:, 0] > 0]
@@ -43,5 +43,4 @@ d = t[:, 1:9] - t[:, 0:8]
 print("  phase durations (median us):", " ".join(f"{np.median(d[:, i]):.2f}" for i in range(8)))
 life_us = t[:, 8] - t[:, 0]
 cyc = (buf[:, 15] - buf[:, 14]).astype(np.float64)
-print(f"  shader clock over wave life: median {np.median(cyc / life_us):.0f} MHz; blocks per wave {rpt // 128}; "
-      f"median cycles per block after the first {np.median((t[:, 8] - t[:, 7]) * np.median(cyc / life_us) / max(1, rpt // 128 - 1)):.0f}")
+print(f"  shader clock over wave life: median {np.median(cyc / life_us):.0f} MHz")
