@@ -12,12 +12,12 @@ from .rollout_ops import gae_returns, gather_columns, gather_rows, normalize_adv
 from .minibatch import MinibatchSource
 from .policy import StackedActors, StackedCritics
 from .rollout import FusedPairedRollout, PairedRollout
-from .fused_policy import PackedNetworks, PolicyPlan
+from .fused_policy import FusedVectorAgent, PackedNetworks, PolicyPlan
 from .mixed_play import MixedPlayRollout, MixedPlaySchedule
 from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments, pairing_segments
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "OvercookedMadrona",
-    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "StackedActors", "StackedCritics", "PairedRollout", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
+    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "StackedActors", "StackedCritics", "PairedRollout", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
 ]

@@ -53,6 +53,7 @@ struct PolicyArgs {
     const int4 *tiles;                  // {row0, nrows, net, flags}
     int n_tiles;
     int tile_per_wg;                    // 1: workgroup i owns tile i; 0: the table's blocks are split evenly over the grid
+    int desync;                         // experiment: the second wavefront of every SIMD starts this many x 64 cycles late
     float *raw;                         // [n_rows][n_out] raw head outputs (tiles without OC_POLICY_TILE_ACT)
     int32_t *actions;                   // [n_rows]
     float *action_logp;                 // [n_rows]
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     const int colstep = H * OC_POLICY_C;
     int loaded_net = -1, n_out = 1;
+    if (a.desync && wave >= 4)
+        for (int i = 0; i < a.desync; i += 100) __builtin_amdgcn_s_sleep(100);
     bool trace_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
@@ -660,6 +663,8 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
+    a.desync = 0;
+    if (const char *env = getenv("OC_POLICY_DESYNC")) a.desync = atoi(env);
     int grid = a.tile_per_wg ? n_tiles : n_cus;
     if (const char *env = getenv("OC_POLICY_GRID")) { const int g = atoi(env); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);

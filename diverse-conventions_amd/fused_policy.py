@@ -173,3 +173,36 @@ class PolicyPlan:
 def gumbel_uniform(seed, counter, row, action):
     """The uniform the kernel used for (row, action) of a draw: lets a test re-derive every sampled action."""
     return float(native.lib().oc_policy_uniform(int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, int(row), int(action)))
+
+
+class FusedVectorAgent:
+    """A partner (or ego) agent for the reference-style loop -- `env.add_partner_agent(agent)`, `agent.get_action(vobs)`
+    (pantheonrl_extension/vectoragent.py; the reference's CentralizedMultiAgent, train/partner_agents.py:78-150, is the
+    multi-convention case) -- whose policies run on the fused MFMA kernel: `segments` = (first kitchen, kitchens,
+    actor net[, critic net]) over the N kitchens of the observation it is handed.  Keeps the last log-probabilities and
+    values in `.action_logp` / `.values` ([N] float32) for a runner that records them."""
+
+    def __init__(self, nets: PackedNetworks, n_kitchens: int, segments, deterministic: bool = False, seed: int = 0):
+        rows = []
+        self.has_critic = False
+        for seg in segments:
+            first, count, actor = int(seg[0]), int(seg[1]), int(seg[2])
+            rows.append((first, count, actor, TILE_ACT))
+            if len(seg) > 3 and seg[3] is not None:
+                rows.append((first, count, int(seg[3]), 0))
+                self.has_critic = True
+        self.plan = PolicyPlan(nets, int(n_kitchens), rows)
+        dev = nets.device
+        self.deterministic, self.seed = deterministic, seed
+        self.actions = torch.zeros(int(n_kitchens), dtype=torch.int32, device=dev)
+        self.action_logp = torch.zeros(int(n_kitchens), dtype=torch.float32, device=dev)
+        self.values = torch.zeros(int(n_kitchens), dtype=torch.float32, device=dev) if self.has_critic else None
+
+    def get_action(self, obs, record: bool = True) -> torch.Tensor:
+        o = obs.obs if obs.obs.is_contiguous() else obs.obs.contiguous()
+        self.plan.forward(o, raw=self.values, actions=self.actions, action_logp=self.action_logp,
+                          deterministic=self.deterministic, seed=self.seed)
+        return self.actions.view(-1, 1)                      # (N, 1), the shape the reference's agents return
+
+    def update(self, rewards, dones) -> None:
+        pass
