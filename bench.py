@@ -188,8 +188,7 @@ def main():
         nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=sds)
         eng2 = OvercookedEngine(params, threads * (2 * k + 1), local)
         ro = FusedPairedRollout(eng2, nets, threads, k)
-        for _ in range(20):
-            ro.step()
+        ro.step(20)
         torch.cuda.synchronize()
         psteps = min(args.steps, 300)
         pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -200,8 +199,7 @@ def main():
         torch.cuda.synchronize()
         pol_us = pe0.elapsed_time(pe1) * 1e3 / psteps
         t1 = time.perf_counter()
-        for _ in range(psteps):
-            ro.step()
+        ro.step(psteps)                                  # policy launch + env launch per step, enqueued from C
         torch.cuda.synchronize()
         step_us = (time.perf_counter() - t1) / psteps * 1e6
         rows = 2 * eng2.num_kitchens

@@ -632,9 +632,10 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         if (w_conv + w_tail_all + 4 * obs1 <= kLds) fc1_lds = true;
         else if (w_conv + w_tail_small + 4 * obs1 > kLds) conv_lds = false;
     }
-    if (const char *env = getenv("OC_POLICY_PLAN")) {                 // diagnostics: "waves,fc1_lds,conv_lds"
+    static const char *const env_plan = getenv("OC_POLICY_PLAN");     // diagnostics: "waves,fc1_lds,conv_lds"
+    if (env_plan) {
         int w = 0, f = 0, c = 0;
-        if (sscanf(env, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
+        if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
     a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
@@ -647,10 +648,13 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
     const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
-    if (lds > 64 * 1024) {
+    static size_t lds_granted[4][2][2] = {};                          // largest opt-in already set per kernel instance
+    size_t &granted = lds_granted[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+        granted = lds;
     }
     // one workgroup per CU; each takes an equal share of the 32-row blocks (workgroups without a share return at once)
     static int n_cus = 0;
@@ -663,13 +667,38 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
-    a.desync = 0;
-    if (const char *env = getenv("OC_POLICY_DESYNC")) a.desync = atoi(env);
+    static const char *const env_desync = getenv("OC_POLICY_DESYNC");
+    a.desync = env_desync ? atoi(env_desync) : 0;
     int grid = a.tile_per_wg ? n_tiles : n_cus;
-    if (const char *env = getenv("OC_POLICY_GRID")) { const int g = atoi(env); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
+    static const char *const env_grid = getenv("OC_POLICY_GRID");
+    if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
+    return OC_OK;
+}
+
+int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
+                      int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
+                      float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
+                      void *stream) {
+    if (!e || !d_obs || !d_actions || !d_reward || !d_done || T < 0)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: NULL pointer or negative T");
+    int64_t shp[5];
+    if (int rc = oc_obs_shape(e, shp)) return rc;
+    if (!shape || shp[2] != shape->width || shp[3] != shape->height)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: the networks' grid does not match the engine's");
+    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t k = in_place ? 0 : t;
+        int8_t *obs_t = d_obs + k * slot, *obs_next = in_place ? d_obs : d_obs + (t + 1) * slot;
+        int32_t *act_t = d_actions + k * rows;
+        if (int rc = oc_policy_forward(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, d_values ? d_values + k * rows : nullptr, act_t,
+                                       d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
+                                       counter0 + static_cast<uint32_t>(t), nullptr, nullptr, stream))
+            return rc;
+        if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n, stream)) return rc;
+    }
     return OC_OK;
 }
 

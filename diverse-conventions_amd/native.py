@@ -28,7 +28,7 @@ SYMBOLS = [
     "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
-    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_uniform",
+    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_uniform", "oc_policy_rollout",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
 
@@ -138,6 +138,7 @@ def lib():
     L.oc_policy_plan_tiles.argtypes = [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, i64]
     L.oc_policy_plan_tiles.restype = i64
     L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp]
+    L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp]
     L.oc_policy_uniform.argtypes = [u32, u32, u32, u32]
     L.oc_policy_uniform.restype = ctypes.c_float
     L.oc_last_error.argtypes = []

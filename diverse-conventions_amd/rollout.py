@@ -97,23 +97,36 @@ class FusedPairedRollout:
         self.logp = torch.zeros((2, n), dtype=torch.float32, device=dev)
         self.values = torch.zeros((2, n), dtype=torch.float32, device=dev) if critic_nets is not None else None
         self.draw = torch.zeros(1, dtype=torch.int32, device=dev)        # device-side draw counter: graph replays differ
+        self.steps_done = 0                                               # host-side draw counter of the eager path
         self.graph = None
 
-    def _policies(self, obs, actions, logp, values):
-        self.plan.forward(obs, raw=values, actions=actions, action_logp=logp, deterministic=self.deterministic,
-                          seed=self.seed, counter=0, device_counter=self.draw)
-        self.draw.add_(1)
-
     def _step(self):
-        self._policies(self.engine.obs, self.actions, self.logp, self.values)
+        # graph capture: the draw counter lives on the device so that every replay samples afresh
+        self.plan.forward(self.engine.obs, raw=self.values, actions=self.actions, action_logp=self.logp,
+                          deterministic=self.deterministic, seed=self.seed, counter=0, device_counter=self.draw)
+        self.draw.add_(1)
         self.engine.step(self.actions)
 
-    def step(self):
-        """One env step for all segments -> (obs, reward, done) engine buffers (overwritten next step)."""
+    def _native(self, T, in_place, obs, actions, logp, values, reward, done):
+        import ctypes
+        from . import native
+        from .fused_policy import _ptr, _shape, _stream
+        e, nets = self.engine, self.nets
+        native.check(native.lib().oc_policy_rollout(
+            e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
+            self.plan.n_tiles, int(T), 1 if in_place else 0, _ptr(obs), _ptr(actions), _ptr(logp), _ptr(values), _ptr(reward), _ptr(done),
+            0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, _stream(e.device)))
+        self.steps_done += int(T)
+
+    def step(self, steps: int = 1):
+        """`steps` env steps for all segments (policy launch + env launch each, enqueued from C in one call)
+        -> (obs, reward, done) engine buffers (overwritten every step)."""
         if self.graph is not None:
-            self.graph.replay()
+            for _ in range(steps):
+                self.graph.replay()
         else:
-            self._step()
+            e = self.engine
+            self._native(steps, True, e.obs, self.actions, self.logp, self.values, e.reward, e.done)
         return self.engine.obs, self.engine.reward, self.engine.done
 
     def capture(self, warmup: int = 3):
@@ -133,8 +146,11 @@ class FusedPairedRollout:
         env step writes `traj.obs[t+1]`, `traj.reward[t]`, `traj.done[t]` -- two launches per step, no copies.
         logp / values: optional float32 [T, 2, N] destinations."""
         traj.start()
-        for t in range(traj.T):
-            self._policies(traj.obs[t], traj.actions[t], None if logp is None else logp[t], None if values is None else values[t])
-            self.engine.step(traj.actions[t], obs=traj.obs[t + 1], reward=traj.reward[t], done=traj.done[t])
+        for name, t in (("logp", logp), ("values", values)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(traj.actions.shape)):
+                raise ValueError(f"{name} must be a contiguous float32 tensor of shape {tuple(traj.actions.shape)}")
+        if values is not None and self.values is None:
+            raise ValueError("this rollout was built without critics")
+        self._native(traj.T, False, traj.obs, traj.actions, logp, values, traj.reward, traj.done)
         traj.t = traj.T
         return traj

@@ -48,12 +48,20 @@ def run_fused(layout, threads, k, steps=200, critics=False):
     cn = [[k + 1 + g for g in range(G)]] * 2 if critics else None
     out = {"layout": layout, "kitchens": n, "segments": G, "conventions": k + 1, "policy": "fused MFMA kernel, f32-class numerics",
            "critics": critics}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "enqueued_from_c"):
         eng = OvercookedEngine(params, n, 0)
         ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=cn)
         if mode == "graph":
             ro.capture()
-        us = time_steps(ro, steps)
+        if mode == "enqueued_from_c":                     # one call enqueues all steps (oc_policy_rollout)
+            ro.step(10)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ro.step(steps)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / steps * 1e6
+        else:
+            us = time_steps(ro, steps)
         out[f"{mode}_us_per_step"] = round(us, 1)
         out[f"{mode}_agent_env_steps_per_s"] = round(2 * n / us * 1e6)
         eng.close()
