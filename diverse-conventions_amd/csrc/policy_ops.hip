@@ -69,7 +69,7 @@ struct PolicyArgs {
 
 __device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, int slot) {
     if (a.trace && lane == 0)
-        a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 16 + slot] = slot >= 14 ? clock64() : wall_clock64();
+        a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 32 + slot] = (slot == 14 || slot == 15) ? clock64() : wall_clock64();
 }
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -132,7 +132,9 @@ template <int NDIG, bool FC1_LDS, bool CONV_LDS>
 __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // (readfirstlane: hipcc cannot prove threadIdx.x >> 6 wave-uniform; without it every block index, bound and LDS-DMA
+    // base derived from it is computed per lane, under exec masks)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     uint8_t *ldsw = lds + a.lds_weight_bytes + static_cast<size_t>(wave) * a.lds_wave_bytes;
 
@@ -210,9 +212,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     const int colstep = H * OC_POLICY_C;
     int loaded_net = -1, n_out = 1;
-    if (a.desync && wave >= 4)
-        for (int i = 0; i < a.desync; i += 100) __builtin_amdgcn_s_sleep(100);
-    bool trace_done = false;
+    bool trace_done = false, trace2_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     // conv result -> fc1 operand: f32(sum of digit accumulators) * scale + bias, ReLU; one accumulator register
@@ -310,16 +310,22 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         __syncthreads();                                              // the network is in LDS
         loaded_net = net;
         stamp(a, wave, lane, 1);
+        if (a.desync && wave >= 4)                                    // experiment: break the lock-step of a SIMD's two waves
+            for (int i = 0; i < a.desync; i += 100) __builtin_amdgcn_s_sleep(100);
     }
 
     for (int blk = first + wave; blk < last; blk += nwaves) {
         const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
         const bool traced = a.trace != nullptr && !trace_done;       // diagnostics: this wavefront's first block of the launch
+        const bool traced2 = a.trace != nullptr && trace_done && !trace2_done;   // ... and, finer, its second
+        if (trace_done) trace2_done = true;
         trace_done = true;
+        if (traced2) stamp(a, wave, lane, 16);
         if (traced) stamp(a, wave, lane, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
         wave_lds_sync();
         if (traced) stamp(a, wave, lane, 3);
+        if (traced2) stamp(a, wave, lane, 17);
 
         // The position loop is software-pipelined by hand: one wavefront per SIMD issues in order, so anything
         // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
@@ -341,9 +347,11 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h1[m][r] = bq[m * 8 + (r >> 2)][r & 3];
         }
+        if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
         v16f x;
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = combine(acc, r);
+        if (traced2) stamp(a, wave, lane, 19);
 
         for (int p = 0; p < P; ++p) {
             v4f w1r[8];                                               // fc1 operands of this position
@@ -362,8 +370,10 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx + 1) & 3], x[sidx], h1[1], 0, 0, 0);
                 x[sidx] = combine(acc, sidx);                         // next position's operand, once this one is consumed
             }
+            if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
         }
         if (traced) stamp(a, wave, lane, 4);
+        if (traced2) stamp(a, wave, lane, 26);
         // dense-layer operands: all issued here, consumed below
         v4f w2r[2][8], whr[8];
 #pragma unroll
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (blk + nwaves < last)
             stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (traced2) stamp(a, wave, lane, 27);
 
         // ---- fc2: h2^T[n2][row] = relu(b2 + W2 relu(h1)), input half m, step f = 2s + m2 ----
 #pragma unroll
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx + 1) & 3], h1[1][sidx], h2[1], 0, 0, 0);
         }
         if (traced) stamp(a, wave, lane, 5);
+        if (traced2) stamp(a, wave, lane, 28);
         // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2[0][r] = fmaxf(h2[0][r], 0.f);
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         for (int sidx = 0; sidx < 16; ++sidx)
             out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[4 + (sidx >> 2)][sidx & 3], h2[1][sidx], out, 0, 0, 0);
         if (traced) stamp(a, wave, lane, 6);
+        if (traced2) stamp(a, wave, lane, 29);
 
         // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
         //      work on their own actions and meet through three lane exchanges ----
@@ -468,6 +481,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             if (a.action_logp) a.action_logp[row] = best_lp;
         }
         if (traced) stamp(a, wave, lane, 7);
+        if (traced2) stamp(a, wave, lane, 30);
     }
   }
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
@@ -705,14 +719,14 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
 /* Diagnostics, deliberately not in the public header: per-wavefront phase stamps of the following launches
  * (tools/trace_policy.py).  enable: allocate and zero; otherwise copy [n_waves][16] stamps out and free. */
 int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves) {
-    const size_t cap = 4096 * 4 * 16 * sizeof(unsigned long long);
+    const size_t cap = 4096 * 4 * 32 * sizeof(unsigned long long);
     if (enable) {
         if (!g_trace && hipMalloc(reinterpret_cast<void **>(&g_trace), cap) != hipSuccess) return OC_ERR_HIP;
         return hipMemset(g_trace, 0, cap) == hipSuccess ? OC_OK : OC_ERR_HIP;
     }
     if (!g_trace) return OC_OK;
     (void)hipDeviceSynchronize();
-    if (host_out) (void)hipMemcpy(host_out, g_trace, static_cast<size_t>(n_waves < 4096 * 4 ? n_waves : 4096 * 4) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (host_out) (void)hipMemcpy(host_out, g_trace, static_cast<size_t>(n_waves < 4096 * 4 ? n_waves : 4096 * 4) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(g_trace);
     g_trace = nullptr;
     return OC_OK;

@@ -28,7 +28,7 @@ L.oc_policy_debug_trace.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int6
 assert L.oc_policy_debug_trace(1, None, 0) == 0
 plan.forward(obs, actions=actions)
 nw = 256 * 8
-buf = np.zeros((nw, 16), dtype=np.uint64)
+buf = np.zeros((nw, 32), dtype=np.uint64)
 assert L.oc_policy_debug_trace(0, buf.ctypes.data_as(ctypes.c_void_p), nw) == 0
 buf = buf[buf[:, 0] > 0]
 t = buf[:, :9].astype(np.float64) / 100.0
@@ -41,6 +41,15 @@ for i, nm in enumerate(names):
     print(f"  {nm:34s} min {c.min():7.2f}  median {np.median(c):7.2f}  max {c.max():7.2f} us")
 d = t[:, 1:9] - t[:, 0:8]
 print("  phase durations (median us):", " ".join(f"{np.median(d[:, i]):.2f}" for i in range(8)))
+fine = buf[buf[:, 30] > 0][:, 16:31].astype(np.float64) / 100.0
+if len(fine):
+    names2 = ["rows wait", "frags(0)+conv(0) issue+frags(1)", "combine(0)"] + [f"position {i}: conv(p+1)+fc1(p)" for i in range(6)] + \
+             ["(loop exit)", "dense operands + next rows DMA issue", "fc2", "head", "epilogue"]
+    d2 = fine[:, 1:] - fine[:, :-1]
+    print(f"  second block of {len(fine)} waves, median us per phase (two waves share each SIMD):")
+    for nm, v in zip(names2, np.median(d2, axis=0)):
+        print(f"    {nm:42s} {v:6.2f}")
+    print(f"    {'whole block':42s} {np.median(fine[:, -1] - fine[:, 0]):6.2f}")
 life_us = t[:, 8] - t[:, 0]
 cyc = (buf[:, 15] - buf[:, 14]).astype(np.float64)
 print(f"  shader clock over wave life: median {np.median(cyc / life_us):.0f} MHz")
