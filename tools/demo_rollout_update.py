@@ -1,62 +1,82 @@
 #!/usr/bin/env python3
-"""How the pieces compose (not a trainer): one PPO-style data-collection segment on the GPU --
-paired rollout (batched actors on both sides + fused env step) written straight into an int8 time-major
-trajectory, batched critics over the whole trajectory, one-launch GAE -- with the timings of each part."""
+"""How the pieces compose (not a trainer): one PPO-style data-collection segment on the GPU and the update-side data
+path behind it, with the time of each part --
+  rollout      FusedPairedRollout.collect: per step ONE fused MFMA policy launch (every convention's actor and the
+               segment's critic, both sides) + ONE env launch writing the next int8 trajectory slot (oc_policy_rollout)
+  bootstrap    one more policy launch for the critics' values of the last observation
+  GAE          oc_gae_returns over the whole [T, N, 2] batch in one launch
+  normalise    oc_advantage_normalize
+  minibatches  one epoch of MinibatchSource.feed_forward_generator (device permutation, int8 row gather, packed scalars)
+"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-from bench_paired_rollout import random_actor
-from diverse_conventions_amd import (OvercookedEngine, StackedActors, StackedCritics, TrajectoryBuffer, gae_returns,
-                                     get_base_layout_params, pairing_segments)
-from diverse_conventions_amd.policy import segment_policy_indices
+from bench_paired_rollout import random_actor, random_critic
+from diverse_conventions_amd import (FusedPairedRollout, MinibatchSource, OvercookedEngine, PackedNetworks, PolicyPlan,
+                                     TrajectoryBuffer, gae_returns, get_base_layout_params, normalize_advantages)
 
 
-def main(layout="cramped_room", threads=1024, k=3, T=200):
+def clock(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t0
+
+
+def main(layout="cramped_room", threads=2048, k=3, T=200, num_mini_batch=4):
     params = get_base_layout_params(layout, T)
     W, H = params["width"], params["height"]
-    segs = pairing_segments(threads, k)
-    n = threads * len(segs)
+    G = 2 * k + 1
+    n = threads * G
     gen = torch.Generator().manual_seed(0)
-    actors = StackedActors([random_actor(W, H, gen=gen) for _ in range(k + 1)], (W, H, 20), "cuda")
-    csd = []
-    for _ in range(len(segs)):                              # one critic per segment (sp, xp0_i, xp1_i)
-        sd = random_actor(W, H, gen=gen)
-        sd["v_out.weight"], sd["v_out.bias"] = torch.randn(1, 64, generator=gen) * 0.1, torch.zeros(1)
-        csd.append(sd)
-    critics = StackedCritics(csd, (W, H, 20), "cuda")
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_actor(W, H, gen=gen) for _ in range(k + 1)],
+                                           critics=[random_critic(W, H, gen) for _ in range(G)])
+    critic_of = [[k + 1 + g for g in range(G)]] * 2                 # one critic per segment (sp, xp0_i, xp1_i), both sides
     eng = OvercookedEngine(params, n, 0)
-    buf = TrajectoryBuffer(eng, T)
-    sel = [actors.select(torch.tensor(segment_policy_indices(segs, side))) for side in ("ego", "partner")]
-    G = len(segs)
+    ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=critic_of)
+    traj = TrajectoryBuffer(eng, T)
+    logp = torch.zeros((T, 2, n), device="cuda")
+    values = torch.zeros((T + 1, 2, n), device="cuda")
+    ro.collect(traj, logp=logp, values=values[:T])                  # warm-up (JIT, first touches)
 
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    obs = buf.start()
-    for t in range(T):
-        acts = [actors.act(obs[p].view(G, threads, W, H, 20), selected=sel[p])[0].view(-1) for p in range(2)]
-        obs, rew, done = buf.step(torch.stack(acts))
-    torch.cuda.synchronize(); t_roll = time.perf_counter() - t0
+    _, t_roll = clock(lambda: ro.collect(traj, logp=logp, values=values[:T]))
+    boot = PolicyPlan(nets, 2 * n, [(side * n + g * threads, threads, critic_of[side][g], 0) for side in range(2) for g in range(G)])
+    _, t_boot = clock(lambda: boot.forward(traj.obs[T], raw=values[T]))
 
-    t0 = time.perf_counter()
-    csel = critics.select(torch.arange(G))
-    ego_obs = buf.agent_view(0)                              # [T+1, N, W, H, C] int8, no copy
-    values = torch.stack([critics.values(ego_obs[t].view(G, threads, W, H, 20), selected=csel).view(n, 1, 1)
-                          for t in range(T + 1)])            # [T+1, N, 1, 1]
-    torch.cuda.synchronize(); t_val = time.perf_counter() - t0
+    def gae():
+        # reference layout [T(+1), N, A, 1]: agent-major engine tensors transposed once (small: 4 B per sample)
+        to_ref = lambda t: t.permute(0, 2, 1).unsqueeze(-1).contiguous()
+        rewards = to_ref(traj.reward.float())
+        masks = torch.ones((T + 1, n, 2, 1), device="cuda")
+        masks[1:] = (1 - traj.done.float()).view(T, n, 1, 1)
+        vals = to_ref(values)
+        returns, adv = gae_returns(rewards, vals, masks, gamma=0.99, gae_lambda=0.95)
+        return rewards, masks, vals, returns, adv
+    gae()                                                           # warm-up: allocator, first launches
+    (rewards, masks, vals, returns, adv), t_gae = clock(gae)
+    normalize_advantages(adv, std_over="active")
+    (adv_n, stats), t_norm = clock(lambda: normalize_advantages(adv, std_over="active"))
 
-    t0 = time.perf_counter()
-    rewards = buf.reward[:, 0].float().view(T, n, 1, 1)
-    masks = torch.ones((T + 1, n, 1, 1), device="cuda")
-    masks[1:] = (1 - buf.done.float()).view(T, n, 1, 1)
-    returns, adv = gae_returns(rewards, values.contiguous(), masks, gamma=0.99, gae_lambda=0.95)
-    torch.cuda.synchronize(); t_gae = time.perf_counter() - t0
-    print(json.dumps({"layout": layout, "kitchens": n, "segments": G, "T": T,
-                      "rollout_s": round(t_roll, 4), "agent_env_steps_per_s": round(2 * n * T / t_roll),
-                      "critic_pass_s": round(t_val, 4), "gae_s": round(t_gae, 5),
-                      "mean_return_per_kitchen": round(float(buf.reward[:, 0].sum()) / n, 3),
-                      "adv_std": round(float(adv.std()), 4), "trajectory_obs_GB": round(buf.obs.numel() / 1e9, 2)}))
+    src = MinibatchSource.from_trajectory(traj, vals, returns, masks, logp.permute(0, 2, 1).unsqueeze(-1).contiguous())
+
+    def epoch():
+        seen = 0
+        for batch in src.feed_forward_generator(adv_n, num_mini_batch=num_mini_batch):
+            seen += batch[1].shape[0]
+        return seen
+    epoch()
+    seen, t_epoch = clock(epoch)
+    print(json.dumps({"layout": layout, "kitchens": n, "segments": G, "conventions": k + 1, "T": T,
+                      "rollout_ms": round(t_roll * 1e3, 2), "agent_env_steps_per_s": round(2 * n * T / t_roll),
+                      "bootstrap_values_ms": round(t_boot * 1e3, 3), "gae_ms": round(t_gae * 1e3, 3),
+                      "advantage_normalise_ms": round(t_norm * 1e3, 3), "minibatch_epoch_ms": round(t_epoch * 1e3, 2),
+                      "samples_per_epoch": seen, "mean_return_per_kitchen": round(float(traj.reward[:, 0].sum()) / n, 3),
+                      "trajectory_obs_GB": round(traj.obs.numel() / 1e9, 2)}))
     eng.close()
 
 
 if __name__ == "__main__":
     main()
+    main("asymmetric_advantages", threads=512)
