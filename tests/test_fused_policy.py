@@ -248,3 +248,25 @@ def test_bad_tiles_are_clamped_not_faulting():
     assert np.isnan(raw[240:]).all() and np.isnan(raw[64:200]).all()
     want = reference_forward(get("a0."), z["obs"], ACTOR_HEAD)
     assert np.abs(raw[200:240] - want[200:240]).max() < TOL and np.abs(raw[:64] - want[:64]).max() < TOL
+
+
+@pytest.mark.gpu
+def test_policy_objects_create_destroy_cycles_do_not_leak():
+    """50 cycles of pack (device kernel) / plan / forward / drop: device memory returns to where it was."""
+    z, get = cases()
+    obs = torch.from_numpy(z["obs"]).cuda()
+    sd = get("a0.")
+    torch.cuda.synchronize()
+    base = None
+    for i in range(50):
+        nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[sd, sd], critics=[get("c0.")])
+        plan = PolicyPlan(nets, 240, [(0, 240, i % 2, TILE_ACT), (0, 240, 2, 0)])
+        a = torch.zeros(240, dtype=torch.int32, device="cuda")
+        v = torch.zeros(240, device="cuda")
+        plan.forward(obs, raw=v, actions=a, deterministic=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy()[:, None], z["a0.det_action"])
+        del nets, plan, a, v
+        if i == 4:
+            base = torch.cuda.memory_allocated()
+    assert torch.cuda.memory_allocated() <= base
