@@ -216,11 +216,17 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     // conv result -> fc1 operand: f32(sum of digit accumulators) * scale + bias, ReLU; one accumulator register
+    // Digit pairs are pre-combined in integer arithmetic (acc_d * 128 + acc_{d+1}: exact, |.| < 2^26), so four digits cost
+    // 2 shift-adds + 2 conversions + 1 fma instead of 4 conversions + 3 fma: a wave's VALU work is not hidden under its MFMAs.
     auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
-        float t = static_cast<float>(acc[0][r]);
-#pragma unroll
-        for (int d = 1; d < NDIG; ++d) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[d][r]));
-        return CONV_LDS ? fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f) : fmaxf(__builtin_fmaf(t, csc[0 + (CONV_LDS ? 0 : r)], cbi[0 + (CONV_LDS ? 0 : r)]), 0.f);
+        float t;
+        if (NDIG == 1) t = static_cast<float>(acc[0][r]);
+        else {
+            t = static_cast<float>(acc[0][r] * 128 + acc[1][r]);
+            if (NDIG == 3) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[2][r]));
+            if (NDIG == 4) t = __builtin_fmaf(t, 16384.0f, static_cast<float>(acc[2][r] * 128 + acc[3][r]));
+        }
+        return CONV_LDS ? fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f) : fmaxf(__builtin_fmaf(t, csc[CONV_LDS ? 0 : r], cbi[CONV_LDS ? 0 : r]), 0.f);
     };
     auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
 #pragma unroll
