@@ -270,3 +270,31 @@ def test_policy_objects_create_destroy_cycles_do_not_leak():
         if i == 4:
             base = torch.cuda.memory_allocated()
     assert torch.cuda.memory_allocated() <= base
+
+
+@pytest.mark.gpu
+def test_kernel_two_million_rows_sampled_against_the_oracle():
+    """Full-size address arithmetic: 2 097 152 rows (2^20 kitchens x 2 sides, 839 MB of observations) in one launch,
+    ragged segment sizes, a sample of rows from every part of the tensor against the numpy restatement."""
+    rng = np.random.default_rng(21)
+    n = 1 << 21
+    actor, critic = random_net(5, 4, 6, ACTOR_HEAD, 5), random_net(5, 4, 1, CRITIC_HEAD, 6)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[actor], critics=[critic])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = (torch.rand((n, 5, 4, 20), device="cuda", generator=g) < 0.12).to(torch.int8) * \
+        torch.randint(1, 21, (n, 5, 4, 20), device="cuda", generator=g, dtype=torch.int8)
+    cuts = [0, 777_777, 1_000_001, n]
+    segs = [(cuts[i], cuts[i + 1] - cuts[i], 0, TILE_ACT) for i in range(3)] + [(cuts[i], cuts[i + 1] - cuts[i], 1, 0) for i in range(3)]
+    plan = PolicyPlan(nets, n, segs)
+    acts = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    logp = torch.full((n, 6), float("nan"), device="cuda")
+    vals = torch.full((n,), float("nan"), device="cuda")
+    plan.forward(obs, raw=vals, actions=acts, logp=logp, deterministic=True)
+    torch.cuda.synchronize()
+    assert int((acts < 0).sum()) == 0 and not bool(torch.isnan(vals).any()) and not bool(torch.isnan(logp).any())
+    pick = np.unique(np.concatenate([rng.integers(0, n, 600), np.arange(0, 40), np.arange(n - 40, n),
+                                     np.arange(777_777 - 40, 777_777 + 40), np.arange(1_000_001 - 40, 1_000_001 + 40)]))
+    o = obs[torch.from_numpy(pick).cuda()].cpu().numpy()
+    want = log_softmax(reference_forward(actor, o, ACTOR_HEAD))
+    assert np.abs(logp[torch.from_numpy(pick).cuda()].cpu().numpy() - want).max() < 8e-6
+    assert np.abs(vals[torch.from_numpy(pick).cuda()].cpu().numpy() - reference_forward(critic, o, CRITIC_HEAD)[:, 0]).max() < 8e-6
