@@ -298,3 +298,35 @@ def test_kernel_two_million_rows_sampled_against_the_oracle():
     want = log_softmax(reference_forward(actor, o, ACTOR_HEAD))
     assert np.abs(logp[torch.from_numpy(pick).cuda()].cpu().numpy() - want).max() < 8e-6
     assert np.abs(vals[torch.from_numpy(pick).cuda()].cpu().numpy() - reference_forward(critic, o, CRITIC_HEAD)[:, 0]).max() < 8e-6
+
+
+@pytest.mark.gpu
+def test_the_binding_shown_in_integration_md_runs():
+    """INTEGRATION.md 2a is code a maintainer would paste into the reference: execute that block as written."""
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n# train/XD/fused_policies\.py\n(.*?)```", text, re.S).group(1)
+    block = block.replace('"diverse-conventions_amd/csrc/liboc_hip.so"', repr(native.LIB_PATH))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:2a", "exec"), ns)
+    z, get = cases()
+
+    class Module:                                        # stands for an R_Actor / R_Critic: only state_dict() is used
+        def __init__(self, sd):
+            self.sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd.items()}
+
+        def state_dict(self):
+            return self.sd
+    fp = ns["FusedPolicies"](5, 4, [Module(get("a0.")), Module(get("a1.")), Module(get("c0."))],
+                             [ACTOR_HEAD, ACTOR_HEAD, CRITIC_HEAD], "cuda")
+    obs = torch.from_numpy(z["obs"]).cuda()
+    tiles = fp.plan([(0, 120, 0, 1), (120, 120, 1, 1), (0, 240, 2, 0)])
+    actions = torch.zeros(240, dtype=torch.int32, device="cuda")
+    logp, values = torch.zeros(240, device="cuda"), torch.zeros(240, device="cuda")
+    fp.act(obs, tiles, actions, logp, values, step=0)
+    torch.cuda.synchronize()
+    assert np.abs(values.cpu().numpy()[:, None] - z["c0.values"]).max() < TOL
+    a = actions.cpu().numpy().astype(np.int64)
+    ref = np.concatenate([z["a0.logits"][:120], z["a1.logits"][120:]])
+    assert np.abs(logp.cpu().numpy() - np.take_along_axis(ref, a[:, None], 1)[:, 0]).max() < TOL_LOGP
