@@ -668,8 +668,10 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
     const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
-    static size_t lds_granted[4][2][2] = {};                          // largest opt-in already set per kernel instance
-    size_t &granted = lds_granted[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
+    static size_t lds_granted[64][4][2][2] = {};                      // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -677,13 +679,14 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         granted = lds;
     }
     // one workgroup per CU; each takes an equal share of the 32-row blocks (workgroups without a share return at once)
-    static int n_cus = 0;
-    if (n_cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+    static int cus_of[64] = {};
+    if (cus_of[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
             return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot query the CU count");
-        n_cus = v;
+        cus_of[dev] = v;
     }
+    const int n_cus = cus_of[dev];
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
