@@ -17,16 +17,27 @@
 // of one layer is then directly the B operand of the next, with no lane movement and no LDS round trip.
 //
 // Bound: MFMA issue.  Cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 32*64) + 64*64 + 32*64;
-// cramped_room (P = 6, 4 digits) 23 040 cycles.  Bytes: rows are read once (W*H*20 B each).
+// cramped_room (P = 6, 4 digits) 23 040 cycles (PMC: SQ_VALU_MFMA_BUSY_CYCLES equals this model exactly).  Bytes: rows
+// are read once (W*H*20 B each).
+//
+// Shape of the kernel (DESIGN.md 9a has the measurements behind each choice):
+//   * a workgroup = up to 8 wavefronts (two per SIMD; the kernel is held to 256 VGPRs and built with
+//     -amdgpu-mfma-vgpr-form so MFMA results are VGPRs the VALU can read) working on rows of ONE network at a time;
+//     which rows: oc_policy_plan_tiles balances one tile per CU, or the kernel splits a short table's 32-row blocks evenly;
+//   * LDS: the network's conv digits and dense-layer weights (copied verbatim from the packed image by LDS-DMA; fc1
+//     only when it fits, otherwise prefetched from L2 per position) + one 32-row staging area per wavefront, filled by
+//     LDS-DMA one block ahead;
+//   * per 32-row block a hand-pipelined loop over the conv positions (conv of p+1 and the operand conversion for p+1 in the
+//     shadow of fc1 of p, fragments of p+2 in flight), then fc2, head and an epilogue in the lanes that hold the outputs.
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
-#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "overcooked_hip.h"
 #include "policy_pack.h"
@@ -64,7 +75,7 @@ struct PolicyArgs {
     int sample;                         // 0: argmax, 1: Gumbel-max draw
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
     int lds_wave_bytes;                 // one wavefront's row-staging area
-    unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*4 + wave][16] stamps, or NULL
+    unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
 };
 
 __device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, int slot) {
