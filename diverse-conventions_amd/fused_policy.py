@@ -83,6 +83,12 @@ class PackedNetworks:
         self._keep = {}
 
     def pack(self, index, state_dict, head=ACTOR_HEAD):
+        """state_dict: an R_Actor / R_Critic of the reference's default configuration -- CNNBase with ReLU (`--use_ReLU`
+        left at its default; the activation has no parameters, so a Tanh network cannot be told apart here) and no
+        recurrent layer (`--use_recurrent_policy` off, as in every training script of the reference)."""
+        if any(k.startswith("rnn.") for k in state_dict):
+            raise NotImplementedError("recurrent policies (rnn.* parameters) are not evaluated by the fused kernel; "
+                                      "the reference's training scripts do not enable them")
         t = lambda k: torch.as_tensor(state_dict[k]).detach().to(device=self.device, dtype=torch.float32).contiguous()
         src = [t(k) for k in _KEYS] + [t(head + ".weight"), t(head + ".bias")]
         hidden, n_out = src[4].shape[0], src[6].shape[0]

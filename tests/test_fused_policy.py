@@ -107,6 +107,16 @@ def test_abi_argument_checks_and_tile_plan():
         plan_tiles([(0, 10, 0, 0)], 100)                     # not a multiple of 32
 
 
+def test_recurrent_state_dicts_are_refused_before_any_gpu_work():
+    import inspect
+    from diverse_conventions_amd import fused_policy
+    src = inspect.getsource(fused_policy.PackedNetworks.pack)
+    assert src.index('startswith("rnn.")') < src.index("oc_policy_pack")        # refused before the device packer runs
+    nets = object.__new__(PackedNetworks)                                        # no GPU needed for the refusal
+    with pytest.raises(NotImplementedError):
+        nets.pack(0, {"rnn.rnn.weight_ih_l0": np.zeros((192, 64), np.float32)})
+
+
 def test_uniform_hash_is_open_interval_and_spread():
     u = np.array([gumbel_uniform(7, c, r, a) for c in range(4) for r in range(200) for a in range(6)])
     assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
