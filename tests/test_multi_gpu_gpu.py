@@ -238,3 +238,44 @@ def test_fused_rollout_collects_a_trajectory_in_place(layout_params):
     assert len(np.unique(acts)) == 6 and (acts[1:] != acts[:-1]).mean() > 0.3          # really sampled, step to step
     assert ro.steps_done == T
     eng.close()
+
+
+@pytest.mark.parametrize("layout", ["random0", "random3", "unident_s", "scenario3", "small_corridor", "corridor"])
+def test_fused_rollout_on_every_lds_plan(layout, layout_params):
+    """The policy kernel chooses a different LDS / wavefront plan per grid size (8 wavefronts with conv digits in LDS;
+    4 with them in LDS; 4 or 2 with them in registers; 1 for 14x9): each one in the integrated rollout, sampled actions
+    re-evaluated by the PyTorch path on the recorded observations, env against the oracle."""
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer
+    from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+    from diverse_conventions_amd import get_base_layout_params
+    params = layout_params[layout] if layout in layout_params else get_base_layout_params(layout, 200)
+    W, H = params["width"], params["height"]
+    P = (W - 2) * (H - 2)
+    rng = np.random.default_rng(W * 31 + H)
+    r = lambda *s: (rng.standard_normal(s) * 0.1).astype(np.float32)
+    sds = [{"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+            "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64),
+            "act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)} for _ in range(2)]
+    threads, k, T = 70, 1, 12
+    n = threads * 3
+    eng = OvercookedEngine(params, n, 0)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=sds)
+    ro = FusedPairedRollout(eng, nets, threads, k, seed=4)
+    traj = TrajectoryBuffer(eng, T)
+    logp = torch.zeros((T, 2, n), device="cuda")
+    ro.collect(traj, logp=logp)
+    ora = oracle.OracleVecEnv(params, n)
+    assert np.array_equal(traj.obs[0].cpu().numpy(), ora.encode())
+    acts = traj.actions.cpu().numpy()
+    for t in range(T):
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(traj.obs[t + 1].cpu().numpy(), oobs) and np.array_equal(traj.reward[t].cpu().numpy(), orew), t
+    sa = StackedActors(sds, (W, H, 20), "cuda")
+    for p, side in enumerate(("ego", "partner")):
+        sel = sa.select(torch.tensor(segment_policy_indices(ro.segments, side)))
+        lp_all = sa.log_probs(traj.obs[:T, p].reshape(T, 3, threads, W, H, 20).permute(1, 0, 2, 3, 4, 5).reshape(3, T * threads, W, H, 20),
+                              selected=sel).view(3, T, threads, 6).permute(1, 0, 2, 3).reshape(T, n, 6)
+        got = lp_all.gather(-1, traj.actions[:, p].long().unsqueeze(-1)).squeeze(-1)
+        assert (got - logp[:, p]).abs().max() < 8e-6
+    assert len(np.unique(acts)) == 6
+    eng.close()
