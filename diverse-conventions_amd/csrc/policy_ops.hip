@@ -343,6 +343,16 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         wave_lds_sync();
         if (traced) stamp(a, wave, lane, 3);
         if (traced2) stamp(a, wave, lane, 17);
+        // A tile with a select code skips the blocks none of whose rows it would write (mixed play: the stretch of
+        // kitchens already forced onto the other policy costs this network nothing).
+        if (((flags >> 8) & 0xff) && a.row_select) {
+            const int want = ((flags >> 8) & 0xff) - 1;
+            const bool mine = col + blk * kRowsPerBlock < nrows && a.row_select[brow + col] == want;
+            if (__ballot(mine) == 0) {
+                if (blk + nwaves < last) stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+                continue;
+            }
+        }
 
         // The position loop is software-pipelined by hand: one wavefront per SIMD issues in order, so anything
         // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
@@ -715,7 +725,7 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                       int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
                       float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
-                      void *stream) {
+                      const int32_t *d_row_select, void *stream) {
     if (!e || !d_obs || !d_actions || !d_reward || !d_done || T < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: NULL pointer or negative T");
     int64_t shp[5];
@@ -729,7 +739,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
         int32_t *act_t = d_actions + k * rows;
         if (int rc = oc_policy_forward(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, d_values ? d_values + k * rows : nullptr, act_t,
                                        d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
-                                       counter0 + static_cast<uint32_t>(t), nullptr, nullptr, stream))
+                                       counter0 + static_cast<uint32_t>(t), nullptr, d_row_select ? d_row_select + t * rows : nullptr, stream))
             return rc;
         if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n, stream)) return rc;
     }

@@ -9,7 +9,7 @@ forced onto policy 0 from step L-1-e of the first episode and from step e+1 of t
 switch times.  Only the forced stretches are kept, and `diaginsert` / `partinsert` shift them so that row e of the
 `[L, L-1]` buffer is [end of episode 1 | rest of episode 2].  All of that is index arithmetic; here it is:
 
-* `MixedPlaySchedule`: kitchen k takes the role of environment `k mod (L-1)`; `choose(step, uniforms)` is the
+* `MixedPlaySchedule`: kitchen k takes the role of environment `k // ceil(N / (L-1))` (contiguous stretches); `choose(step, uniforms)` is the
   reference's `mix_mask` for a whole `[N]` vector on the device, `gather_index()` the placement map of the two
   inserts as one row index, so the mixed-play buffer is ONE gather out of a time-aligned trajectory.
 * `MixedPlayRollout`: the 2L-step collection itself -- per step one fused policy launch in which the two candidate
@@ -30,7 +30,10 @@ class MixedPlaySchedule:
         if length < 2:
             raise ValueError("episode length must be at least 2")
         self.L, self.N, self.device = int(length), int(n_kitchens), torch.device(device)
-        self.lane = torch.arange(self.N, device=self.device) % (self.L - 1)         # the reference's environment index
+        # the reference's environment index, in contiguous stretches of kitchens: the kitchens already forced onto the
+        # trained policy then form one range, whose 32-row blocks the partner networks' tiles skip outright
+        reps = -(-self.N // (self.L - 1))
+        self.lane = torch.arange(self.N, device=self.device) // reps
 
     def forced_main(self, step: int) -> torch.Tensor:
         """bool [N]: kitchens whose `mix_mask` entry the reference zeroes at wall step `step` (0 .. 2L-1)."""
@@ -44,6 +47,13 @@ class MixedPlaySchedule:
     def choose(self, step: int, uniforms: torch.Tensor) -> torch.Tensor:
         """uniforms f32 [..., N] -> int32 [..., N]: 1 where the partner convention plays, 0 where the trained policy does."""
         return ((uniforms < 0.5) & ~self.forced_main(step)).to(torch.int32)
+
+    def choose_all(self, uniforms: torch.Tensor) -> torch.Tensor:
+        """uniforms f32 [2L, ..., N] -> int32 [2L, ..., N]: `choose` for every wall step at once."""
+        L, e = self.L, self.lane
+        step = torch.arange(2 * L, device=self.device).view(2 * L, *([1] * (uniforms.dim() - 1)))
+        forced = torch.where(step >= L, e < (step - L), (step > 0) & (e >= (L - 1 - step)))
+        return ((uniforms < 0.5) & ~forced).to(torch.int32)
 
     def source_step(self) -> torch.Tensor:
         """int64 [L, N]: wall step whose turn data the reference stores at buffer time t of kitchen k."""
@@ -88,16 +98,22 @@ class MixedPlayRollout:
     def collect(self, uniforms=None):
         """Run the two episodes.  uniforms: optional f32 [2L, 2, N] (index 0 = the ego side's draw, 1 = the partner's,
         the order the reference draws them in); default: `torch.rand` on the device."""
-        e, n, T = self.engine, self.engine.num_kitchens, 2 * self.L
+        import ctypes
+        from . import native
+        from .fused_policy import _ptr, _shape, _stream
+        e, n, T, nets = self.engine, self.engine.num_kitchens, 2 * self.L, self.nets
         e.reset_all()
         self.traj.start()
-        for i in range(T):
-            u = uniforms[i] if uniforms is not None else torch.rand((2, n), device=e.device, generator=self.generator)
-            ch = self.schedule.choose(i, u)                                           # [2, N]: ego draw, partner draw
-            self.choice[i, self.ego_id], self.choice[i, 1 - self.ego_id] = ch[0], ch[1]
-            self.plan.forward(self.traj.obs[i], raw=self.values[i], actions=self.traj.actions[i], action_logp=self.logp[i],
-                              deterministic=self.deterministic, seed=self.seed, counter=i, row_select=self.choice[i])
-            e.step(self.traj.actions[i], obs=self.traj.obs[i + 1], reward=self.traj.reward[i], done=self.traj.done[i])
+        if uniforms is None:
+            uniforms = torch.rand((T, 2, n), device=e.device, generator=self.generator)
+        ch = self.schedule.choose_all(uniforms)                                         # [2L, 2, N]: ego draw, partner draw
+        self.choice[:, self.ego_id], self.choice[:, 1 - self.ego_id] = ch[:, 0], ch[:, 1]
+        # all 2L steps (policy launch with the per-row choices of the step + env launch) enqueued by one call
+        native.check(native.lib().oc_policy_rollout(
+            e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
+            self.plan.n_tiles, T, 0, _ptr(self.traj.obs), _ptr(self.traj.actions), _ptr(self.logp), _ptr(self.values),
+            _ptr(self.traj.reward), _ptr(self.traj.done), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, 0,
+            _ptr(self.choice), _stream(e.device)))
         self.traj.t = T
         return self
 

@@ -138,7 +138,7 @@ def lib():
     L.oc_policy_plan_tiles.argtypes = [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, i64]
     L.oc_policy_plan_tiles.restype = i64
     L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp]
-    L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp]
+    L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
     L.oc_policy_uniform.argtypes = [u32, u32, u32, u32]
     L.oc_policy_uniform.restype = ctypes.c_float
     L.oc_last_error.argtypes = []

@@ -115,7 +115,7 @@ class FusedPairedRollout:
         native.check(native.lib().oc_policy_rollout(
             e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
             self.plan.n_tiles, int(T), 1 if in_place else 0, _ptr(obs), _ptr(actions), _ptr(logp), _ptr(values), _ptr(reward), _ptr(done),
-            0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, _stream(e.device)))
+            0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, None, _stream(e.device)))
         self.steps_done += int(T)
 
     def step(self, steps: int = 1):

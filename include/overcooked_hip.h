@@ -258,11 +258,13 @@ float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t 
  * (train/XD/xd_player.py:177-230).  in_place = 0: time-major trajectory -- d_obs int8 [T+1][P][N][W][H][C] with slot 0
  * holding the current observation (oc_observe), d_actions int32 [T][P][N], d_action_logp / d_values f32 [T][P][N] or
  * NULL, d_reward int32 [T][P][N], d_done int32 [T][N]; step t reads slot t and writes slot t+1.  in_place != 0: one
- * slot of each, overwritten every step.  The draw counter of step t is counter0 + t. */
+ * slot of each, overwritten every step.  The draw counter of step t is counter0 + t.  d_row_select: NULL, or int32 [T][2N]
+ * per-row policy choices of every step (always time-major), as oc_policy_forward takes them for one step: the whole
+ * mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) is then one call. */
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                       int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
                       float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
-                      void *stream);
+                      const int32_t *d_row_select, void *stream);
 
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);

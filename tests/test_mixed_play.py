@@ -36,6 +36,7 @@ def test_schedule_matches_reference_choice_and_placement():
         for step in range(2 * L):
             ch = s.choose(step, torch.from_numpy(g["draws"][step]))             # [2, L-1]
             assert np.array_equal(ch.numpy(), acted[step])
+        assert np.array_equal(s.choose_all(torch.from_numpy(g["draws"])).numpy(), acted)
         assert np.array_equal(s.source_step().numpy(), g["obs"][:L, :, 0, 0, 0, 0].astype(np.int64))
         # the whole reference buffer is one gather out of time-aligned per-step data: rebuild every stored quantity
         # from what each (wall step, env, agent) produced in the reference run
@@ -58,14 +59,13 @@ def test_schedule_many_kitchens_repeats_the_staircase():
     L, reps = 7, 5
     s = MixedPlaySchedule(L, reps * (L - 1))
     want = buffer_source_steps(L)
-    assert np.array_equal(s.source_step().numpy(), np.tile(want, (1, reps)))
+    assert np.array_equal(s.source_step().numpy(), np.repeat(want, reps, axis=1))       # kitchen k plays environment k // reps
     u = torch.rand(2, reps * (L - 1))
     for step in range(2 * L):
         ch = s.choose(step, u).numpy()
-        for r in range(reps):
+        for r in range(reps):                                   # every reps-th kitchen: one full copy of the reference's envs
             for side in range(2):
-                assert np.array_equal(ch[side, r * (L - 1):(r + 1) * (L - 1)],
-                                      policy_choice(L, step, u[side, r * (L - 1):(r + 1) * (L - 1)].numpy()))
+                assert np.array_equal(ch[side, r::reps], policy_choice(L, step, u[side, r::reps].numpy()))
 
 
 @pytest.mark.gpu
@@ -95,8 +95,8 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
     for i in range(2 * L):
         ch = ro.choice[i]
         for side in range(2):
-            want = policy_choice(L, i, uniforms[i, side, :L - 1].cpu().numpy())
-            assert np.array_equal(ch[side, :L - 1].cpu().numpy(), want)
+            want = policy_choice(L, i, uniforms[i, side, ::reps].cpu().numpy())
+            assert np.array_equal(ch[side, ::reps].cpu().numpy(), want)
             obs = ro.traj.obs[i, side].unsqueeze(0)
             a = torch.stack([sa.act(obs, torch.tensor([k]), deterministic=True)[0].view(-1) for k in range(2)])
             v = torch.stack([sc.values(obs, torch.tensor([k])).view(-1) for k in range(2)])
@@ -107,7 +107,7 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
         assert np.array_equal(ro.traj.obs[i + 1].cpu().numpy(), oobs) and np.array_equal(ro.traj.done[i].cpu().numpy(), odone)
         assert int(odone.sum()) == (n if i in (L - 1, 2 * L - 1) else 0)
     buf = ro.buffer()
-    src = np.tile(buffer_source_steps(L), (1, reps))                     # [L, N]
+    src = np.repeat(buffer_source_steps(L), reps, axis=1)                # [L, N]: kitchen k plays environment k // reps
     assert np.array_equal(buf["source_step"].cpu().numpy(), src)
     tobs, tact = ro.traj.obs.cpu().numpy(), acts
     for t in range(L):
