@@ -80,7 +80,14 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
             kitchen.n_step(a)
         n1 += 512
     python_1env = 2 * n1 / (time.perf_counter() - t0)
-    return {"value": value, "unit": "agent-env steps/s", "cores": best_threads, "kind": "port",
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": value, "unit": "agent-env steps/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model,
+            "usable_cores": cores,
             "sample": f"{steps} steps x {kitchens} kitchens ({el:.1f} s), same layout and action law as the GPU run, "
                       f"C oracle with OpenMP over kitchens, best of {[1] + candidates} threads on a host with {cores} usable cores",
             "value_1core": single,
