@@ -65,6 +65,16 @@ class TrajectoryBuffer:
             self.records[0].copy_(self.records[self.T])
         self.t = 0
 
+    def episode_returns(self):
+        """Mean return of the episodes that ENDED inside the buffer, per kitchen -> (mean f32 [N], count int64 [N]); NaN where
+        none ended.  What the reference's runners accumulate as `running_score` and push into `scores` at every done
+        (train/XD/xd_player.py:224-230); feed it to `sharding.segment_scores`.  Assumes slot 0 starts an episode."""
+        r = self.reward[:self.t, 0].to(torch.float32)                 # the shared reward (sum over players)
+        d = self.done[:self.t].to(torch.float32)
+        upto_last_done = (r.cumsum(0) * d).amax(0)                     # rewards are never negative
+        count = d.sum(0)
+        return upto_last_done / count, count.to(torch.int64)
+
     def agent_view(self, agent: int):
         """Observations of one player as the reference buffer indexes them: [T+1, N, W, H, C] (int8 view)."""
         return self.obs[:, agent]

@@ -118,4 +118,8 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
             assert np.array_equal(buf["value_preds"][t, :, k].cpu().numpy(), ro.values[w, :, k].cpu().numpy())
             assert float(buf["masks"][t, 0, k]) == (0.0 if w in (L - 1, 2 * L - 1) else 1.0)
     assert int(buf["choice"].abs().sum()) == 0                           # every kept step was played by the trained policy
+    mean_ret, count = ro.traj.episode_returns()                          # two episodes of L steps ended in the 2L-step buffer
+    rew = ro.traj.reward[:, 0].cpu().numpy().astype(np.float64)
+    assert np.array_equal(count.cpu().numpy(), np.full(n, 2))
+    assert np.allclose(mean_ret.cpu().numpy(), rew.sum(0) / 2)
     eng.close()

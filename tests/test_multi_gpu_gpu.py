@@ -236,6 +236,8 @@ def test_fused_rollout_collects_a_trajectory_in_place(layout_params):
             a = traj.actions[:, p, seg.start:seg.stop].long()
             assert (lp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1) - logp[:, p, seg.start:seg.stop]).abs().max() < 4e-6
     assert len(np.unique(acts)) == 6 and (acts[1:] != acts[:-1]).mean() > 0.3          # really sampled, step to step
+    mean_ret, count = traj.episode_returns()                       # horizon 200 > T: no episode ended inside the buffer
+    assert int(count.sum()) == 0 and bool(torch.isnan(mean_ret).all())
     assert ro.steps_done == T
     eng.close()
 
