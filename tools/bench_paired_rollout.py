@@ -99,6 +99,8 @@ if __name__ == "__main__":
     print(json.dumps(run_fused("cramped_room", 4096, 7)), flush=True)
     print(json.dumps(run_fused("cramped_room", 4096, 7, critics=True)), flush=True)
     print(json.dumps(run_fused("asymmetric_advantages", 1024, 7, critics=True)), flush=True)
+    # one GPU's share of BASELINE config 4: asymmetric_advantages, 65 536 kitchens over 8 GPUs, 16 conventions (31 segments)
+    print(json.dumps(run_fused("asymmetric_advantages", 8192 // 31, 15, critics=True)), flush=True)
     print(json.dumps(run("cramped_room", 546, 7)), flush=True)          # config-3-sized: 8190 kitchens
     print(json.dumps(run("cramped_room", 4096, 7)), flush=True)         # 61 440 kitchens
     print(json.dumps(run("cramped_room", 4096, 7, dtype=torch.bfloat16)), flush=True)
