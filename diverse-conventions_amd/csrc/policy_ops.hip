@@ -40,9 +40,9 @@
 #include <vector>
 
 #include "overcooked_hip.h"
+#include "oc_internal.h"
 #include "policy_pack.h"
 
-int oc_internal_fail(int code, const char *fmt, ...);      // overcooked_engine.hip: sets oc_last_error()
 
 namespace {
 
@@ -569,6 +569,7 @@ int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const fl
     if (reinterpret_cast<uintptr_t>(d_dst) & 15) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_pack: d_dst must be 16-byte aligned");
     const oc_policy_layout L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
     const unsigned grid = static_cast<unsigned>((L.total / 4 + 255) / 256);
+    const OcDeviceScope on_device(oc_device_of_pointer(d_dst));
     hipLaunchKernelGGL(oc_policy_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), L, w,
                        static_cast<uint32_t *>(d_dst));
     const hipError_t err = hipGetLastError();
@@ -689,8 +690,12 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
     const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
+    // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
+    int dev = oc_device_of_pointer(d_packed);
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
+    if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
+    const OcDeviceScope on_device(dev);
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
     static size_t lds_granted[64][4][2][2] = {};                      // largest opt-in already set per device and kernel instance
     size_t &granted = lds_granted[dev][shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     if (lds > 64 * 1024 && lds > granted) {
@@ -733,6 +738,8 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
     if (!shape || shp[2] != shape->width || shp[3] != shape->height)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: the networks' grid does not match the engine's");
     const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
+    const OcDeviceScope on_device(oc_device_id(e));       // once for the whole rollout; the per-step calls then find it current
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: cannot make device %d current", oc_device_id(e));
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
         int8_t *obs_t = d_obs + k * slot, *obs_next = in_place ? d_obs : d_obs + (t + 1) * slot;

@@ -194,7 +194,9 @@ OC_HD inline uint32_t oc_policy_hash(uint32_t seed, uint32_t counter, uint32_t r
     return x;
 }
 OC_HD inline float oc_policy_uniform_from_hash(uint32_t x) {
-    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1): never 0, never 1
+    // 23 bits: (x >> 9) + 0.5 <= 8388607.5 is exact in f32 (24 significant bits), so u lies in
+    // [2^-24, 1 - 2^-24]: never 0, never 1 (with 24 bits the top value rounded to even, i.e. to 1.0)
+    return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 #endif  // OC_POLICY_PACK_H

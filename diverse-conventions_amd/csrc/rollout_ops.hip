@@ -13,6 +13,7 @@
 #include <cstdint>
 
 #include "overcooked_hip.h"
+#include "oc_internal.h"
 
 // Build with -ffp-contract=off (native.build does): __fadd_rn & co. are plain operators in HIP, and an FMA
 // rounds once where the reference's separate torch ops round twice.
@@ -119,6 +120,7 @@ extern "C" int oc_gae_returns(const float *d_rewards, const float *d_value_preds
     a.gamma_lambda = static_cast<float>(gamma * gae_lambda);
     a.denormalize = denormalize; a.vn_mean = vn_mean; a.vn_std = vn_std;
     a.proper_time_limits = proper_time_limits;
+    const OcDeviceScope on_device(oc_device_of_pointer(d_returns));
     const unsigned grid = static_cast<unsigned>((M + 255) / 256);
     hipLaunchKernelGGL(oc_gae_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
@@ -250,6 +252,7 @@ extern "C" int oc_advantage_normalize(const float *d_adv, const float *d_active_
     if ((reinterpret_cast<uintptr_t>(d_adv) & 15) || (reinterpret_cast<uintptr_t>(d_active_masks) & 15) ||
         (reinterpret_cast<uintptr_t>(d_out) & 15) || (reinterpret_cast<uintptr_t>(d_workspace) & 7))
         return OC_ERR_INVALID_ARG;
+    const OcDeviceScope on_device(oc_device_of_pointer(d_adv));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long n4 = n >> 2;
     int blocks = static_cast<int>(std::min<long long>(kStatBlocks, std::max<long long>(1, (n4 + 255) / 256)));
@@ -388,6 +391,7 @@ extern "C" int oc_gather_rows(const void *d_src, int64_t src_rows, int32_t row_b
     const int mode = dst_dtype == 1 ? GATHER_I8_TO_F32 : ((row_bytes & 15) == 0 ? GATHER_COPY16 : GATHER_COPY4);
     a.units = mode == GATHER_COPY16 ? row_bytes / 16 : row_bytes / 4;
     a.inv_units = 1.0f / static_cast<float>(a.units);
+    const OcDeviceScope on_device(oc_device_of_pointer(d_dst));
     const long long n_batches = (n_rows + 63) >> 6;
     const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_batches + 3) / 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -418,6 +422,7 @@ extern "C" int oc_gather_columns(int32_t n_cols, const void *const *d_src, const
     a.n_rows = n_rows;
     a.row_mul = row_mul;
     a.row_add = row_add;
+    const OcDeviceScope on_device(oc_device_of_pointer(d_index));
     const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_rows + 255) / 256));
     hipLaunchKernelGGL(oc_gather_columns_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
@@ -495,6 +500,7 @@ extern "C" int oc_pack_columns(int32_t n_cols, const void *const *d_src, int64_t
     a.n_cols = n_cols;
     a.n_rows = n_rows;
     a.packed = static_cast<u32x4 *>(d_packed);
+    const OcDeviceScope on_device(oc_device_of_pointer(d_packed));
     const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_rows + 255) / 256));
     hipLaunchKernelGGL(oc_pack_columns_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
@@ -521,6 +527,7 @@ extern "C" int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t
     a.src_rows = src_rows;
     a.row_mul = row_mul;
     a.row_add = row_add;
+    const OcDeviceScope on_device(oc_device_of_pointer(d_packed));
     const int grid = static_cast<int>(std::min<long long>(256 * 8, (n_rows + 255) / 256));
     hipLaunchKernelGGL(oc_gather_records_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;

@@ -41,7 +41,6 @@ class MinibatchSource:
             if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[:3]) != (want_t, self.N, self.A):
                 raise ValueError(f"{k} must be contiguous float32 [{want_t}, {self.N}, {self.A}, ...]")
         self.num_actions = num_actions
-        self._packed, self._packed_key = None, None
 
     @classmethod
     def from_trajectory(cls, traj, value_preds, returns, masks, action_log_probs, active_masks=None, **kw):
@@ -70,21 +69,20 @@ class MinibatchSource:
         return [perm[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(num_mini_batch)]   # :326-327
 
     def _records(self, advantages):
-        """Sample records of the six scalar columns (+ advantages), rebuilt when any of them was written since."""
-        cols = [self.cols[k] for k in _SCALARS] + ([advantages] if advantages is not None else [])
-        key = tuple((t.data_ptr(), t._version) for t in cols)                   # in-place writes bump _version
-        if self._packed is None or self._packed_key != key:
-            rows = self.T * self.N * self.A
-            self._packed, self._packed_key = pack_columns(cols, rows), key
-        return self._packed
-
-    def _batch(self, idx, obs_rows, advantages, row_mul, row_add, obs_dtype, norm_stats):
-        obs_batch = gather_rows(self.obs.view(-1, *self.obs.shape[3:]), obs_rows, dtype=obs_dtype)
+        """Sample records of the six scalar columns (+ advantages): packed afresh at the start of every generator call
+        (one streaming pass).  Nothing is cached across calls: the columns are written in place through raw pointers by
+        this library's own kernels (gae_returns, normalize_advantages, the policy kernels), which torch's version
+        counters do not see, and the caching allocator hands the same address out again for a new tensor."""
         if advantages is not None and (advantages.dtype != torch.float32 or not advantages.is_contiguous()
                                        or advantages.numel() != self.T * self.N * self.A):
             raise ValueError("advantages must be contiguous float32 [T, N, A, 1]")
+        cols = [self.cols[k] for k in _SCALARS] + ([advantages] if advantages is not None else [])
+        return pack_columns(cols, self.T * self.N * self.A)
+
+    def _batch(self, packed, idx, obs_rows, advantages, row_mul, row_add, obs_dtype, norm_stats):
+        obs_batch = gather_rows(self.obs.view(-1, *self.obs.shape[3:]), obs_rows, dtype=obs_dtype)
         n_cols = len(_SCALARS) + (advantages is not None)
-        vals = gather_records(self._records(advantages), n_cols, idx, row_mul, row_add,
+        vals = gather_records(packed, n_cols, idx, row_mul, row_add,
                               norm_col=len(_SCALARS) if (advantages is not None and norm_stats is not None) else -1,
                               norm_stats=norm_stats)
         out = dict(zip(_SCALARS + ("adv_targ",), vals))
@@ -105,11 +103,12 @@ class MinibatchSource:
         advantages [T, N, A, 1] f32 or None; with `norm_stats` (from normalize_advantages(..., out=None) statistics) raw
         advantages are normalised while they are gathered.  obs_dtype torch.float32 (reference) or torch.int8."""
         T, N, A = self.T, self.N, self.A
+        packed = self._records(advantages)
         for idx in self._sampler(T * N * A, num_mini_batch, mini_batch_size, perm, generator):
             a = idx % A
             tn = idx // A
             obs_rows = ((tn // N) * A + a) * N + tn % N                           # (t, a, n) in the agent-major trajectory
-            yield self._batch(idx.contiguous(), obs_rows, advantages, 1, 0, obs_dtype, norm_stats)
+            yield self._batch(packed, idx.contiguous(), obs_rows, advantages, 1, 0, obs_dtype, norm_stats)
 
     def partial_ff_generator(self, advantages, agent, num_mini_batch=None, mini_batch_size=None, perm=None, generator=None,
                              obs_dtype=torch.float32, norm_stats=None):
@@ -117,6 +116,7 @@ class MinibatchSource:
         T, N, A = self.T, self.N, self.A
         if not 0 <= agent < A:
             raise IndexError("agent index out of range")
+        packed = self._records(advantages)
         for idx in self._sampler(T * N, num_mini_batch, mini_batch_size, perm, generator):
             obs_rows = ((idx // N) * A + agent) * N + idx % N
-            yield self._batch(idx.contiguous(), obs_rows, advantages, A, agent, obs_dtype, norm_stats)
+            yield self._batch(packed, idx.contiguous(), obs_rows, advantages, A, agent, obs_dtype, norm_stats)

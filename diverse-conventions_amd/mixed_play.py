@@ -89,6 +89,9 @@ class MixedPlayRollout:
                 rows.append((side * n, n, critic, tile_select(choice)))
         self.plan = PolicyPlan(nets, 2 * n, rows, rows_per_tile=rows_per_tile)
         self.ego_id, self.seed, self.deterministic, self.generator = ego_id, seed, deterministic, generator
+        # running draw counter: the kernel's Gumbel noise is hash(seed, counter + t, row, action), so every collection
+        # must start where the previous one stopped or it would replay the same noise (as FusedPairedRollout.steps_done does)
+        self.draws_done = 0
         T, dev = 2 * self.L, engine.device
         self.traj = TrajectoryBuffer(engine, T)
         self.logp = torch.zeros((T, 2, n), dtype=torch.float32, device=dev)
@@ -112,8 +115,9 @@ class MixedPlayRollout:
         native.check(native.lib().oc_policy_rollout(
             e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
             self.plan.n_tiles, T, 0, _ptr(self.traj.obs), _ptr(self.traj.actions), _ptr(self.logp), _ptr(self.values),
-            _ptr(self.traj.reward), _ptr(self.traj.done), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, 0,
-            _ptr(self.choice), _stream(e.device)))
+            _ptr(self.traj.reward), _ptr(self.traj.done), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF,
+            self.draws_done & 0xFFFFFFFF, _ptr(self.choice), _stream(e.device)))
+        self.draws_done += T
         self.traj.t = T
         return self
 

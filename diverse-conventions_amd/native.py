@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
-HEADERS = [os.path.join(CSRC, "policy_pack.h")]
+HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h")]
 KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")
 KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: KERNEL_HEADER as a C++ raw string
 INCLUDE = os.path.join(REPO_ROOT, "include")

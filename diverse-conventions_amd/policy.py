@@ -80,8 +80,10 @@ class StackedActors:
             a = logp.argmax(dim=-1, keepdim=True)
         else:
             # Gumbel-max: one fused elementwise kernel + argmax, capturable in a HIP graph
-            u = torch.rand(logp.shape, device=logp.device, dtype=logp.dtype, generator=generator).clamp_(1e-12, 1.0)
-            a = (logp - torch.log(-torch.log(u))).argmax(dim=-1, keepdim=True)
+            # u drawn in f32 and kept inside (0, 1): u == 1 (reachable when a low-precision draw rounds up) would make
+            # the noise +inf and force that action whatever its probability
+            u = torch.rand(logp.shape, device=logp.device, dtype=torch.float32, generator=generator).clamp_(2.0 ** -24, 1.0 - 2.0 ** -24)
+            a = (logp.float() - torch.log(-torch.log(u))).argmax(dim=-1, keepdim=True)
         return a, logp.gather(-1, a)
 
 

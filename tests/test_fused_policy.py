@@ -123,6 +123,18 @@ def test_uniform_hash_is_open_interval_and_spread():
     assert len(np.unique(u)) > 0.99 * len(u)
 
 
+def test_uniform_hash_extremes_stay_inside_the_open_interval():
+    """u = ((x >> 9) + 0.5) / 2^23 in f32: the largest and smallest hashes must not round to 1.0 / 0.0 (with 24 bits the
+    top value did: -log(u) = 0, Gumbel noise +inf, the action forced whatever its probability)."""
+    hi = (np.float32(0xFFFFFFFF >> 9) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    lo = (np.float32(0) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    assert hi.dtype == np.float32 and 0.0 < lo and hi < 1.0 and np.isfinite(np.log(-np.log(hi))) and np.isfinite(np.log(-np.log(lo)))
+    # and the library agrees with this formula on real hashes
+    for row in range(50):
+        u = gumbel_uniform(3, 5, row, 2)
+        assert 2.0 ** -24 <= u <= 1.0 - 2.0 ** -24
+
+
 # ------------------------------------------------------------------------------------------------------ GPU parity
 def _run(nets, n_rows, segments, obs, rows_per_tile=128, **kw):
     plan = PolicyPlan(nets, n_rows, segments, rows_per_tile=rows_per_tile)

@@ -206,3 +206,34 @@ def test_sample_records_follow_in_place_updates():
     for k, (a, b) in enumerate(zip(first, second)):
         assert torch.equal(a + 1.0, b[5])
         assert np.array_equal(b[10].cpu().numpy(), c["ff_adv_targ"][k] * 2.0)
+
+
+@pytest.mark.gpu
+def test_minibatches_see_writes_made_through_raw_pointers():
+    """This library's own kernels write their outputs through raw device pointers (no torch version bump): a persistent
+    `returns` buffer refilled by gae_returns and advantages normalised in place between two generator calls must be what
+    the second call yields -- nothing may be cached across calls."""
+    import torch
+    from diverse_conventions_amd import gae_returns, normalize_advantages
+    i, c = CASES[0]
+    src = source_of(c)
+    T, N, A = src.T, src.N, src.A
+    g = torch.Generator(device="cuda").manual_seed(3)
+    adv = torch.randn((T, N, A, 1), device="cuda", generator=g)
+    first = [(b[6].clone(), b[10].clone()) for b in src.feed_forward_generator(adv, 3, perm=c["ff_perm"])]
+    # same tensors, same data_ptr, same _version: refill `returns` and normalise `adv` in place with the native kernels
+    rewards = torch.randn((T, N, A, 1), device="cuda", generator=g)
+    v0 = src.cols["returns"]._version, adv._version
+    gae_returns(rewards, src.cols["value_preds"], src.cols["masks"], returns=src.cols["returns"])
+    normalize_advantages(adv, out=adv)
+    assert (src.cols["returns"]._version, adv._version) == v0, "the premise of this test: raw-pointer writes do not bump _version"
+    second = list(src.feed_forward_generator(adv, 3, perm=c["ff_perm"]))
+    perm = torch.as_tensor(c["ff_perm"]).cuda()
+    mb = (T * N * A) // 3
+    ret_flat, adv_flat = src.cols["returns"][:-1].reshape(-1, 1), adv.reshape(-1, 1)
+    changed = False
+    for k, b in enumerate(second):
+        idx = perm[k * mb:(k + 1) * mb]
+        assert torch.equal(b[6], ret_flat[idx]) and torch.equal(b[10], adv_flat[idx])
+        changed |= not torch.equal(b[6], first[k][0])
+    assert changed

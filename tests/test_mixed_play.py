@@ -123,3 +123,32 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
     assert np.array_equal(count.cpu().numpy(), np.full(n, 2))
     assert np.allclose(mean_ret.cpu().numpy(), rew.sum(0) / 2)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_two_collections_draw_fresh_action_noise(layout_params):
+    """The Gumbel noise of the sampled actions is hash(seed, draw counter + t, row, action): a second collect() with the same
+    weights, the same coin flips and the same seed must continue the counter, not replay the first collection's noise."""
+    from diverse_conventions_amd import OvercookedEngine, PackedNetworks
+    from diverse_conventions_amd.fused_policy import gumbel_uniform
+    from diverse_conventions_amd.mixed_play import MixedPlayRollout
+    z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
+    pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}
+    L, n = 6, 40
+    eng = OvercookedEngine(dict(layout_params["simple"], horizon=L), n, 0)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[pick("a0."), pick("a1.")], critics=[pick("c0."), pick("c1.")])
+    ro = MixedPlayRollout(eng, nets, L, main=(0, 2), partner=(1, 3), seed=77, rows_per_tile=32)
+    uniforms = torch.rand((2 * L, 2, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    a1 = ro.collect(uniforms).traj.actions.clone()
+    lp1 = ro.logp.clone()
+    assert ro.draws_done == 2 * L
+    a2 = ro.collect(uniforms).traj.actions.clone()
+    assert ro.draws_done == 4 * L
+    # step 0 sees the same start observation and the same policy choice in both collections: only the noise can differ
+    assert not torch.equal(a1[0], a2[0]), "the second collection replayed the first one's sampling noise"
+    assert torch.equal(lp1[0].isfinite(), torch.ones_like(lp1[0], dtype=torch.bool))
+    # and the draw of step t of the second collection is the one the exported hash gives for counter 2L + t
+    u_first = np.array([gumbel_uniform(77, 0, r, a) for r in range(4) for a in range(6)])
+    u_second = np.array([gumbel_uniform(77, 2 * L, r, a) for r in range(4) for a in range(6)])
+    assert not np.array_equal(u_first, u_second)
+    eng.close()
