@@ -249,6 +249,22 @@ class OvercookedEngine:
                                                       obs_global.shape[1] * per_kitchen, self._stream()))
         return obs_global
 
+    def encode_trajectory_into(self, records, obs_global, kitchen_offset):
+        """Featurise T blocks of n records (`records` [T, n, rec/4], block t possibly strided) into kitchens
+        [kitchen_offset, kitchen_offset+n) of every time slot of an int8 [T, P, N_total, W, H, C] tensor: one launch."""
+        T, n = records.shape[0], records.shape[1]
+        per_kitchen = self.size * CHANNELS
+        if (obs_global.dim() != 6 or not obs_global.is_contiguous() or obs_global.shape[0] != T
+                or kitchen_offset + n > obs_global.shape[2]):
+            raise ValueError("obs_global must be a contiguous [T, P, N_total, W, H, C] tensor that holds the block")
+        if records.stride(2) != 1 or records.stride(1) != records.shape[2] or records.shape[2] * records.element_size() != self.record_bytes:
+            raise ValueError("every time step's records must be one contiguous [n, rec/4] block")
+        n_total = obs_global.shape[2]
+        dst = obs_global.data_ptr() + kitchen_offset * per_kitchen
+        native.check(self._L.oc_encode_trajectory(self._handle, _ptr(records), n, T, records.stride(0) * records.element_size(),
+                                                  ctypes.c_void_p(dst), n_total * per_kitchen, 2 * n_total * per_kitchen, self._stream()))
+        return obs_global
+
     def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0, waves_per_cu=0):
         native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush, waves_per_cu))
 

@@ -14,8 +14,10 @@ LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
 HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h")]
-KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")
-KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: KERNEL_HEADER as a C++ raw string
+KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")              # ahead-of-time (generic) build
+KERNEL_COMMON = os.path.join(CSRC, "oc_step_common.h")              # the two headers hiprtc compiles per engine / group
+KERNEL_BODY = os.path.join(CSRC, "oc_step_body.h")
+KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: both headers as C++ raw strings
 INCLUDE = os.path.join(REPO_ROOT, "include")
 
 OC_OK = 0
@@ -25,7 +27,9 @@ STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", 
 # every symbol include/overcooked_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
-    "oc_encode_states", "oc_encode_states_strided", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
+    "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
+    "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
+    "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
     "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_uniform", "oc_policy_rollout",
@@ -59,16 +63,18 @@ class OvercookedNativeError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, os.path.join(INCLUDE, "overcooked_hip.h")])
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, KERNEL_COMMON, KERNEL_BODY,
+                                                                    os.path.join(INCLUDE, "overcooked_hip.h")])
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
-    # the kernel header is also embedded as text: oc_create() re-compiles it per engine with hiprtc
-    with open(KERNEL_HEADER) as f:
-        text = f.read()
-    assert ')OCKSRC"' not in text
+    # the kernel headers are also embedded as text: oc_create() / oc_group_create() re-compile them with hiprtc
     with open(KERNEL_SRC_INC, "w") as f:
-        f.write('// generated from oc_step_kernel.h by native.build() -- do not edit\n'
-                'static const char oc_step_kernel_src[] = R"OCKSRC(' + text + ')OCKSRC";\n')
+        f.write('// generated from oc_step_common.h / oc_step_body.h by native.build() -- do not edit\n')
+        for name, path in (("oc_step_common_src", KERNEL_COMMON), ("oc_step_body_src", KERNEL_BODY)):
+            with open(path) as h:
+                text = h.read()
+            assert ')OCKSRC"' not in text
+            f.write('static const char ' + name + '[] = R"OCKSRC(' + text + ')OCKSRC";\n')
     # -ffp-contract=off: rollout_ops.hip must round like the reference's separate torch ops (no FMA); the
     # engine itself has no floating point
     # -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs (policy_ops.hip reads them with VALU ops; the
@@ -148,6 +154,20 @@ def lib():
     L.oc_debug_jit_compile.argtypes = [ctypes.POINTER(OcLayoutParams), i64, ctypes.c_char_p, ctypes.POINTER(i64),
                                        ctypes.c_char_p, i64]
     L.oc_abi_version.argtypes = []
+    L.oc_encode_trajectory.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp]
+    pvp = ctypes.POINTER(vp)
+    L.oc_group_create.argtypes = [pvp, ctypes.c_int32, pvp]
+    L.oc_group_destroy.argtypes = [vp]
+    L.oc_group_size.argtypes = [vp]
+    L.oc_group_size.restype = ctypes.c_int32
+    L.oc_group_step.argtypes = [vp, pvp, i32, pvp, pvp, pvp, vp]
+    L.oc_group_observe.argtypes = [vp, pvp, vp]
+    L.oc_group_rollout_timed.argtypes = [vp, pvp, i32, i64, i64, pvp, pvp, pvp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.oc_group_set_tuning.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), i32, i32]
+    L.oc_group_build_info.argtypes = [vp]
+    L.oc_group_build_info.restype = ctypes.c_char_p
+    L.oc_debug_jit_compile_group.argtypes = [ctypes.POINTER(OcLayoutParams), ctypes.POINTER(i64), ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, i64]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:          # default restype: int status
@@ -169,6 +189,19 @@ def jit_compile_check(params, num_kitchens=4096, arch="gfx950"):
     check(lib().oc_debug_jit_compile(ctypes.byref(make_params(params)), num_kitchens, arch.encode(), ctypes.byref(size),
                                      log, len(log)))
     return size.value
+
+
+def jit_compile_check_group(params_list, kitchens_list, num_cus=256, arch="gfx950"):
+    """Compile the group module (one launch over several engines) without a GPU.
+    -> (code object size, [(kitchens per wavefront group, blocks)] per engine)."""
+    n = len(params_list)
+    arr = (OcLayoutParams * n)(*[make_params(p) for p in params_list])
+    counts = (ctypes.c_int64 * n)(*[int(k) for k in kitchens_list])
+    plan = (ctypes.c_int32 * (2 * n))()
+    size = ctypes.c_int64(0)
+    log = ctypes.create_string_buffer(8192)
+    check(lib().oc_debug_jit_compile_group(arr, counts, n, num_cus, arch.encode(), ctypes.byref(size), plan, log, len(log)))
+    return size.value, [(plan[2 * i], plan[2 * i + 1]) for i in range(n)]
 
 
 def make_params(params):

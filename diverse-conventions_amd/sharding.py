@@ -67,34 +67,51 @@ def local_segments(threads_total: int, n_conventions: int, world: int, rank: int
 
 
 class TrajectoryExchange:
-    """All-gather of compact time-major trajectory shards.
+    """All-gather of compact time-major trajectory shards: ONE collective per update.
 
-    Every rank contributes tensors whose leading dims are [T, n_local, ...]; the result keeps peers'
-    shards as separate leading-dim blocks, [world, T, n_local, ...], which is exactly what
-    `all_gather_into_tensor` produces -- no permute, no staging copy.  Shards must be equal-sized
-    (use a kitchen count divisible by the world size)."""
+    `gather_trajectory` packs the four compact fields of a rank's rollout into one flat int32 buffer
+    [records | actions | reward | done] (one concatenation pass over 4S+16 bytes per kitchen-step), issues a single
+    `all_gather_into_tensor` on it (RCCL over xGMI on the GPU box, gloo in the CPU tests: both take flat 1-D buffers)
+    and hands back per-field views of the result, peers in rank order: [world, T, ...].  Shards must be equal-sized
+    (use a kitchen count divisible by the world size); errors of the collective propagate."""
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collectives = 0                      # all-gathers issued so far (one per gather_trajectory)
 
     def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        """[...] -> [world, ...], rank r's tensor at index r."""
         local = local.contiguous()
         if self.world == 1:
             return local.unsqueeze(0)
-        out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        try:
-            dist.all_gather_into_tensor(out, local, group=self.group)
-        except (RuntimeError, NotImplementedError):          # backend without the fused form
-            dist.all_gather(list(out.unbind(0)), local, group=self.group)
-        return out
+        out = torch.empty((self.world * local.numel(),), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.view(-1), group=self.group)
+        self.collectives += 1
+        return out.view((self.world,) + tuple(local.shape))
+
+    @staticmethod
+    def _as_words(t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.int32:
+            raise ValueError("compact trajectory fields are int32 (records as int32 words)")
+        return t.contiguous().view(-1)
 
     def gather_trajectory(self, records, actions, reward, done):
-        """records int32 [T, n, rec/4]; actions [T, P, n]; reward [T, n]; done [T, n]
-        -> dict of [world, ...] tensors (peer r's shard at index r)."""
-        return {"records": self.all_gather(records), "actions": self.all_gather(actions),
-                "reward": self.all_gather(reward), "done": self.all_gather(done)}
+        """records int32 [T, n, rec/4]; actions int32 [T, P, n]; reward int32 [T, n]; done int32 [T, n]
+        -> dict of [world, ...] views of ONE gathered buffer (peer r's shard at index r)."""
+        fields = (("records", records), ("actions", actions), ("reward", reward), ("done", done))
+        flat = [self._as_words(t) for _, t in fields]
+        sizes = [f.numel() for f in flat]
+        pad = (-sum(sizes)) % 4                   # every rank's block starts 16-byte aligned (the encode kernel reads uint4)
+        if pad:
+            flat.append(torch.zeros(pad, dtype=torch.int32, device=flat[0].device))
+        got = self.all_gather(torch.cat(flat))    # [world, words]
+        out, off = {}, 0
+        for (name, t), sz in zip(fields, sizes):
+            out[name] = got[:, off:off + sz].view((got.shape[0],) + tuple(t.shape))
+            off += sz
+        return out
 
     def featurize(self, engine, records_all, t, out=None):
         """Observation of every kitchen of every rank at time t from the gathered records:
@@ -104,6 +121,16 @@ class TrajectoryExchange:
             out = torch.empty((2, world * n, engine.width, engine.height, 20), dtype=torch.int8, device=records_all.device)
         for r in range(world):
             engine.encode_states_into(records_all[r, t], out, r * n)
+        return out
+
+    def featurize_all(self, engine, records_all, out=None):
+        """The whole gathered trajectory re-featurised: int8 [T, P, world*n, W, H, C] from records [world, T, n, rec/4],
+        ONE launch per peer for all T time steps (oc_encode_trajectory)."""
+        world, T, n = records_all.shape[:3]
+        if out is None:
+            out = torch.empty((T, 2, world * n, engine.width, engine.height, 20), dtype=torch.int8, device=records_all.device)
+        for r in range(world):
+            engine.encode_trajectory_into(records_all[r], out, r * n)
         return out
 
 

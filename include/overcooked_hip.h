@@ -50,7 +50,7 @@ extern "C" {
 #define OC_MAX_TILES 255
 #define OC_MAX_PLAYERS 2
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 1
+#define OC_ABI_VERSION 2
 
 typedef enum {
     OC_OK = 0,
@@ -138,6 +138,38 @@ int oc_encode_states(oc_engine *e, const void *d_states, int64_t n, int8_t *d_ob
  * drop a peer's shard at its kitchen offset inside a larger [P][N_total][W][H][C] tensor. */
 int oc_encode_states_strided(oc_engine *e, const void *d_states, int64_t n, int8_t *d_obs, int64_t obs_player_stride,
                              void *stream);
+
+/* A whole gathered trajectory of one peer re-featurised in ONE launch (the receive side of the compact exchange,
+ * SURVEY.md 8(e)): T blocks of n records, block t at d_states + t * state_step_stride bytes; viewer v's [n][W][H][C]
+ * plane of block t goes to d_obs + t * obs_step_stride + v * obs_player_stride bytes (strides in bytes). */
+int oc_encode_trajectory(oc_engine *e, const void *d_states, int64_t n, int64_t T, int64_t state_step_stride, int8_t *d_obs,
+                         int64_t obs_player_stride, int64_t obs_step_stride, void *stream);
+
+/* ---- several engines stepped by ONE launch ---------------------------------------------------------------------------
+ * The reference evaluates and trains on its five layouts side by side, one simulator object per layout
+ * (train/env_utils.py:26 generate_env, train/test_all.sh:8; BASELINE configs 3 and 5), i.e. five Manager::step calls per
+ * joint step.  A group is the MI355X counterpart of that set: up to 8 engines on one GPU -- different layouts, sizes,
+ * horizons; each still usable on its own -- whose step (or observe) is a single kernel launch.  The group module holds one
+ * specialised kernel body per distinct layout and hands every engine a share of the persistent wavefronts in proportion to
+ * its tiles, so the constant folding of the per-engine build is kept and the four extra launch boundaries are not paid.
+ * The pointer tables are HOST arrays of oc_group_size() device pointers, in the order of oc_group_create; buffers, dtypes
+ * and results per engine are exactly those of oc_step / oc_observe.  Without a usable hiprtc (or with obs buffers that are
+ * not 16-byte aligned) the calls fall back to one launch per engine, same results (oc_group_build_info says which). */
+typedef struct oc_group oc_group;
+int oc_group_create(oc_engine *const *engines, int32_t n_engines, oc_group **out);
+int oc_group_destroy(oc_group *g);                    /* the engines stay alive and belong to the caller */
+int32_t oc_group_size(const oc_group *g);
+int oc_group_step(oc_group *g, const void *const *d_actions, int action_dtype, int8_t *const *d_obs, int32_t *const *d_reward,
+                  int32_t *const *d_done, void *stream);
+int oc_group_observe(oc_group *g, int8_t *const *d_obs, void *stream);
+/* T joint steps enqueued from C and bracketed by hipEvents on `stream` (the group counterpart of oc_rollout_timed):
+ * engine i consumes its action tape d_actions[i] = [T_act][P][N_i] cyclically; outputs overwritten in place. */
+int oc_group_rollout_timed(oc_group *g, const void *const *d_actions, int action_dtype, int64_t T_act, int64_t T, int8_t *const *d_obs,
+                           int32_t *const *d_reward, int32_t *const *d_done, void *stream, float *elapsed_ms);
+/* Launch tuning of the group (performance only): kitchens per wavefront group for every engine (host array of
+ * oc_group_size() ints; NULL or 0 entries = chosen from the joint batch), passes per flush, persistent wavefronts per CU. */
+int oc_group_set_tuning(oc_group *g, const int32_t *kitchens_per_wave, int passes_per_flush, int waves_per_cu);
+const char *oc_group_build_info(const oc_group *g);
 
 /* State import / export.  get/set are synchronous host copies (tests, checkpoints);
  * export/import are stream-ordered device-to-device copies of `count` records starting at `first`. */

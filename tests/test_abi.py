@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(native.SYMBOLS) == declared
     for name in declared:
         assert getattr(L, name) is not None, name
-    assert L.oc_abi_version() == 1
+    assert L.oc_abi_version() == 2
 
 
 def test_layout_struct_matches_header():
@@ -112,4 +112,4 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
-    assert out[0] == "-2" and "2-player" in out[1] and out[2] == "1" and out[3] == "0"
+    assert out[0] == "-2" and "2-player" in out[1] and out[2] == "2" and out[3] == "0"

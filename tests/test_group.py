@@ -1,0 +1,218 @@
+"""Several engines stepped by ONE launch (oc_group_*): the reference's five-layout set (train/env_utils.py:26 one simulator
+per layout, train/test_all.sh:8; BASELINE configs 3 and 5).  CPU: the group module compiles for gfx950 and the launch
+geometry balances the wavefronts; GPU: bit-exact against the oracle, against the engines stepped one by one, and for
+every way the group can be configured."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import oracle
+
+CLASSIC = ["simple", "unident_s", "random1", "random0", "random3"]
+
+
+# ------------------------------------------------------------------------------------------------------------ CPU
+def test_group_module_compiles_and_plan_gives_one_group_per_wavefront(layout_params):
+    from diverse_conventions_amd import native
+    ps = [layout_params[n] for n in CLASSIC]
+    size, plan = native.jit_compile_check_group(ps, [8192] * 5)
+    assert size > 50_000
+    tiles = []
+    for p, (kpw, blocks) in zip(ps, plan):
+        S = p["width"] * p["height"]
+        assert kpw % 4 == 0 and 4 <= kpw <= 64 and (kpw * S * 5) % 4 == 0
+        assert blocks == -(-8192 // kpw), "config 3 fits one group per wavefront: nobody gets two"
+        tiles.append(kpw * S)
+    assert sum(b for _, b in plan) <= 8 * 256
+    even = sum(8192 * p["width"] * p["height"] for p in ps) / (8 * 256)          # tiles per wavefront of a perfect split
+    assert max(tiles) <= 1.15 * even, f"unbalanced wavefronts: {tiles} tiles per group, {even:.0f} if split evenly"
+
+
+def test_group_plan_large_batches_share_wavefronts_by_tiles(layout_params):
+    from diverse_conventions_amd import native
+    ps = [layout_params[n] for n in CLASSIC]
+    _, plan = native.jit_compile_check_group(ps, [65536] * 5)
+    blocks = np.array([b for _, b in plan], dtype=np.float64)
+    tiles = np.array([65536 * p["width"] * p["height"] for p in ps], dtype=np.float64)
+    assert blocks.sum() <= 8 * 256 and blocks.sum() >= 8 * 256 - 5
+    assert np.abs(blocks / blocks.sum() - tiles / tiles.sum()).max() < 0.01
+
+
+def test_group_module_dedupes_equal_layouts_and_takes_tiny_engines(layout_params):
+    from diverse_conventions_amd import native
+    p = layout_params["simple"]
+    one, _ = native.jit_compile_check_group([p], [64])
+    two, plan = native.jit_compile_check_group([p, p], [64, 64])
+    assert plan[0] == plan[1]
+    assert two < 1.2 * one, "two engines of one layout and tuning share one kernel body"
+    _, plan = native.jit_compile_check_group([p, layout_params["unident_s"]], [1, 3])
+    assert all(b >= 1 for _, b in plan)
+
+
+def test_group_rejects_bad_arguments():
+    import ctypes
+    from diverse_conventions_amd import native
+    L = native.lib()
+    out = ctypes.c_void_p()
+    assert L.oc_group_create(None, 1, ctypes.byref(out)) == -1
+    arr = (ctypes.c_void_p * 9)()
+    assert L.oc_group_create(arr, 9, ctypes.byref(out)) == -1 and b"1..8" in L.oc_last_error()
+    assert L.oc_group_create(arr, 1, ctypes.byref(out)) == -1 and b"NULL" in L.oc_last_error()
+    assert L.oc_group_step(None, None, 0, None, None, None, None) == -1
+    assert L.oc_group_size(None) == 0 and L.oc_group_destroy(None) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+def _mixed_actions(layout, T, n, seed, p_guided=0.85):
+    g = load_golden(os.path.join(GOLDEN, f"guided_{layout}.npz"))["actions"]
+    rng = np.random.default_rng(seed)
+    base = np.broadcast_to(g[:T, :, None], (T, 2, n))
+    rnd = rng.integers(0, 6, size=(T, 2, n))
+    keep = rng.random((T, 1, n)) < p_guided
+    return np.where(keep, base, rnd).astype(np.int32)
+
+
+def _make(layout_params, names, counts, horizons=None):
+    from diverse_conventions_amd import EngineGroup, OvercookedEngine
+    horizons = horizons or [200] * len(names)
+    params = [dict(layout_params[nm], horizon=h) for nm, h in zip(names, horizons)]
+    engines = [OvercookedEngine(p, n, 0) for p, n in zip(params, counts)]
+    return params, engines, EngineGroup(engines)
+
+
+@pytest.mark.gpu
+def test_group_step_is_one_launch_bit_exact_vs_oracle(layout_params):
+    """The five classic layouts with ragged, different kitchen counts and different horizons in one launch per step:
+    obs, reward, done of every kitchen at every step and the full state at the end, against the oracle."""
+    counts, horizons = [1003, 517, 777, 64, 1290], [200, 150, 200, 90, 200]
+    params, engines, grp = _make(layout_params, CLASSIC, counts, horizons)
+    assert "one launch" in grp.build_info and "5 specialised bodies" in grp.build_info, grp.build_info
+    T = 230
+    acts = [_mixed_actions(nm, T, n, seed=3 + i) for i, (nm, n) in enumerate(zip(CLASSIC, counts))]
+    oras = [oracle.OracleVecEnv(p, n, nthreads=8) for p, n in zip(params, counts)]
+    for o, want in zip(grp.observe(), oras):
+        assert np.array_equal(o.cpu().numpy(), want.encode())
+    dacts = [torch.from_numpy(a).cuda() for a in acts]
+    total = 0
+    for t in range(T):
+        obs, rew, done = grp.step([a[t] for a in dacts])
+        for i, ora in enumerate(oras):
+            oobs, orew, odone = ora.step(acts[i][t])
+            assert np.array_equal(done[i].cpu().numpy(), odone), f"step {t} engine {i}: done"
+            assert np.array_equal(rew[i].cpu().numpy(), orew), f"step {t} engine {i}: reward"
+            assert np.array_equal(obs[i].cpu().numpy(), oobs), f"step {t} engine {i}: obs"
+            total += int(orew[0].sum())
+    assert total > 0
+    for e, ora in zip(engines, oras):
+        for x, y in zip(e.get_state(), ora.get_state()):
+            assert np.array_equal(x, y)
+    grp.close(close_engines=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "int64", "tuned", "nine_waves", "no_jit", "time_major", "misaligned"])
+def test_group_equals_engines_stepped_one_by_one(mode, layout_params, monkeypatch):
+    """Whatever the configuration -- action dtype, launch geometry, the per-engine fallback, fresh destination slots
+    (non-temporal stores), obs buffers that are not 16-byte aligned -- a group step leaves exactly what stepping its
+    engines one after the other leaves."""
+    from diverse_conventions_amd import EngineGroup, OvercookedEngine
+    names, counts, T = ["random3", "simple", "simple", "random0"], [300, 257, 64, 411], 40
+    if mode == "no_jit":
+        monkeypatch.setenv("OC_NO_JIT", "1")
+    params = [layout_params[n] for n in names]
+    solo = [OvercookedEngine(p, n, 0) for p, n in zip(params, counts)]
+    engines = [OvercookedEngine(p, n, 0) for p, n in zip(params, counts)]
+    grp = EngineGroup(engines)
+    if mode == "no_jit":
+        assert "OC_NO_JIT" in grp.build_info
+    else:
+        assert "3 specialised bodies" in grp.build_info, grp.build_info       # the two `simple` engines share one
+    if mode == "tuned":
+        grp.set_tuning([4, 8, 52, 12], passes_per_flush=2)
+    if mode == "nine_waves":
+        grp.set_tuning(None, 0, 9)
+    rng = np.random.default_rng(8)
+    dt = torch.int64 if mode == "int64" else torch.int32
+    acts = [torch.from_numpy(rng.integers(0, 6, size=(T, 2, n))).to(dt).cuda() for n in counts]
+    if mode == "time_major":
+        slots = [torch.zeros((T,) + tuple(e.obs.shape), dtype=torch.int8, device="cuda") for e in engines]
+    if mode == "misaligned":
+        raw = [torch.zeros(e.obs.numel() + 16, dtype=torch.int8, device="cuda") for e in engines]
+        odd = [r[4:4 + e.obs.numel()].view(e.obs.shape) for r, e in zip(raw, engines)]
+        assert all(o.data_ptr() % 16 == 4 for o in odd)
+    for t in range(T):
+        kw = {}
+        if mode == "time_major":
+            kw["obs"] = [s[t] for s in slots]
+        if mode == "misaligned":
+            kw["obs"] = odd
+        obs, rew, done = grp.step([a[t] for a in acts], **kw)
+        for i, s in enumerate(solo):
+            so, sr, sd = s.step(acts[i][t])
+            assert torch.equal(obs[i], so) and torch.equal(rew[i], sr) and torch.equal(done[i], sd), f"step {t} engine {i}"
+    for e, s in zip(engines, solo):
+        assert torch.equal(e.export_states(), s.export_states())
+    grp.close(close_engines=True)
+    for s in solo:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_config3_shape_in_one_launch(layout_params):
+    """BASELINE config 3 as one launch per joint step: the five classic layouts x 8192 kitchens, 8 conventions in the
+    reference's 15 pairing segments (every (policy, side) pair its own action stream); 256 sampled kitchens per layout
+    against the oracle at every step, all kitchens' rewards/dones against a second engine set stepped one by one."""
+    from diverse_conventions_amd import pairing_segments
+    n, k, T = 8192, 7, 210
+    threads = n // (2 * k + 1)
+    segs = pairing_segments(threads, k)
+    rng = np.random.default_rng(9)
+    tapes = rng.integers(0, 6, size=(k + 1, 2, T, threads)).astype(np.int32)
+    acts = np.full((T, 2, n), 4, dtype=np.int32)
+    for s in segs:
+        acts[:, 0, s.start:s.stop] = tapes[s.ego_policy, 0]
+        acts[:, 1, s.start:s.stop] = tapes[s.partner_policy, 1]
+    sample = np.sort(rng.choice(n, size=256, replace=False))
+    params, engines, grp = _make(layout_params, CLASSIC, [n] * 5)
+    assert "one launch" in grp.build_info, grp.build_info
+    oras = [oracle.OracleVecEnv(p, len(sample), nthreads=8) for p in params]
+    dacts = torch.from_numpy(acts).cuda()
+    idx = torch.from_numpy(sample).cuda()
+    for t in range(T):
+        obs, rew, done = grp.step([dacts[t]] * 5)
+        for i, ora in enumerate(oras):
+            oobs, orew, odone = ora.step(acts[t][:, sample])
+            assert np.array_equal(obs[i][:, idx].cpu().numpy(), oobs), f"step {t} layout {CLASSIC[i]}"
+            assert np.array_equal(rew[i][:, idx].cpu().numpy(), orew) and np.array_equal(done[i][idx].cpu().numpy(), odone)
+        if t in (199, 200):
+            assert all(int(d.sum()) == (n if t == 199 else 0) for d in done)
+    grp.close(close_engines=True)
+
+
+@pytest.mark.gpu
+def test_encode_trajectory_is_the_per_step_encode(layout_params):
+    """oc_encode_trajectory: T strided record blocks -> T time slots of a larger tensor in one launch, equal to one
+    oc_encode_states_strided call per time step; neighbouring kitchens of the destination stay untouched."""
+    from diverse_conventions_amd import OvercookedEngine
+    for name, n, T in (("unident_s", 37, 9), ("simple", 200, 5), ("random1", 5, 33)):
+        eng = OvercookedEngine(layout_params[name], n, 0)
+        r4 = eng.record_bytes // 4
+        rng = np.random.default_rng(n)
+        acts = torch.from_numpy(rng.integers(0, 6, size=(T, 2, n)).astype(np.int32)).cuda()
+        padded = torch.zeros((T, n * r4 + 8), dtype=torch.int32, device="cuda")            # rows with a gap: a strided source
+        recs = padded[:, :n * r4].view(T, n, r4)
+        for t in range(T):
+            eng.step(acts[t])
+            recs[t].copy_(eng.export_states())
+        n_total, off = n + 11, 7
+        want = torch.full((T, 2, n_total, eng.width, eng.height, 20), -7, dtype=torch.int8, device="cuda")
+        got = want.clone()
+        for t in range(T):
+            eng.encode_states_into(recs[t].contiguous(), want[t], off)
+        eng.encode_trajectory_into(recs, got, off)
+        assert torch.equal(got, want), name
+        assert int((got[:, :, :off] != -7).sum()) == 0 and int((got[:, :, off + n:] != -7).sum()) == 0
+        eng.close()

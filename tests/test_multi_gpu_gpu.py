@@ -34,6 +34,10 @@ def test_peer_shards_refeaturised_in_place(layout_params):
         obs = ex.featurize(engines[0], gathered, t)
         assert obs.shape == (2, total, 8, 5, 20)
         assert np.array_equal(obs.cpu().numpy(), want[t]), t
+    # the whole trajectory of every peer: one launch per peer for all T steps
+    all_obs = ex.featurize_all(engines[0], gathered)
+    assert all_obs.shape == (T, 2, total, 8, 5, 20)
+    assert np.array_equal(all_obs.cpu().numpy(), np.stack(want))
     for e in engines:
         e.close()
 

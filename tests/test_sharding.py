@@ -71,9 +71,11 @@ def _worker(rank, world, port, q):
         ex = TrajectoryExchange()
         got = ex.gather_trajectory(torch.from_numpy(np.stack(recs)), torch.from_numpy(acts_all[:, :, sl].copy()),
                                    torch.from_numpy(np.stack(rews)), torch.from_numpy(np.stack(dones)))
+        ok_one = ex.collectives == 1                  # the four fields travel in ONE all-gather
         # every rank must now hold the full batch, peers in rank order, equal to a single-process run
         ref = oracle.OracleVecEnv(params, total)
-        ok = got["records"].shape == (world, T, shard.count, rec_bytes // 4)
+        ok = ok_one and got["records"].shape == (world, T, shard.count, rec_bytes // 4)
+        ok &= got["records"].data_ptr() % 16 == 0 and got["records"][1].data_ptr() % 16 == 0    # uint4-readable by the encode kernel
         for t in range(T):
             _, r, d = ref.step(acts_all[t])
             full = pack_states(*ref.get_state(), rec_bytes).view(np.int32)
