@@ -93,7 +93,7 @@ __device__ __forceinline__ int interact(bool act, uint32_t terr, uint32_t &t, ui
 // BATCH (!STEP only): `a` describes batch_items blocks of n_kitchens records each, item b at state +
 // b * state_batch_stride (uint4) with its planes at obs + b * obs_batch_stride (bytes): a whole gathered trajectory
 // of one peer re-featurised in one launch.
-template <bool STEP, bool ACT64, bool VEC16, int QN, bool NT = false, bool FUSED = false, bool BATCH = false>
+template <bool STEP, bool ACT64, bool VEC16, int QN, int SM = SM_PLAIN, bool FUSED = false, bool BATCH = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id, const int n_blocks) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const LdsView L = carve(lds, a);
@@ -361,7 +361,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                     const uint32_t *src = L.stage[v];
                     if (VEC16) {
                         const int nfull = gbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
-                        for (int c = lane; c < nfull; c += kWave) store16<NT>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
+                        for (int c = lane; c < nfull; c += kWave) store16<SM>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
                         const int rem = (gbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
                         if (lane < rem) store4(dst + nfull * 16 + lane * 4, src[nfull * 4 + lane]);
                     } else {
@@ -397,6 +397,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
             for (int q = 0; q < QN; ++q)
                 if (lane + q * kWave < nq) {
                     const uint32_t *sp = L.state + loff[q];
+                    // plain stores: the records are re-read by the next launch, and sending them write-through as well
+                    // measured slower (12.9 vs 12.2 us at 65 536 kitchens)
                     dst[lane + q * kWave] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
                 }
         }

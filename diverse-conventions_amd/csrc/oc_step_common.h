@@ -231,14 +231,24 @@ __device__ __forceinline__ int sanitize_action(int a) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// one global_store_dwordx4: the caller guarantees 16-byte alignment (VEC16 launches only)
-// NT: non-temporal form for destinations that are not rewritten soon (a fresh trajectory slot every step):
-// measured 13.5 vs 14.7 us per launch into a 10 GB time-major buffer, but 13.5 vs 13.2 us when the same
-// 52 MB buffer is overwritten in place (it then lives in the Infinity Cache), so the host picks per launch.
-template <bool NT>
+// one global_store_dwordx4 (VEC16 launches only).  SM = store mode of the observation planes:
+//   0 plain: the lines stay dirty in the XCD's L2 until evicted or until the end-of-kernel write-back;
+//   1 non-temporal, for destinations that are not rewritten soon (a fresh trajectory slot every step): measured 13.5
+//     vs 14.7 us per launch into a 10 GB time-major buffer, but 13.5 vs 13.2 us when the same 52 MB buffer is
+//     overwritten in place (it then lives in the Infinity Cache);
+//   2 / 3 write-through (sc1 / sc0 sc1): the bytes leave L2 as they are written instead of waiting, dirty, for the
+//     write-back at the kernel boundary -- for batches whose whole output fits the 32 MB of L2 that write-back is
+//     otherwise a serial tail of bytes / 6 TB/s behind the last wavefront (MI355X_MICROARCH.md, "boundary" row).
+// The write-through forms have no builtin for 16-byte stores, hence the inline asm; nothing in the kernel reads what
+// these stores write, so the asm needs no memory clobber, and stores the compiler does not count only make its own
+// vmcnt waits more conservative (vmcnt retires in order).
+enum : int { SM_PLAIN = 0, SM_NT = 1, SM_SC1 = 2, SM_SC0SC1 = 3 };
+template <int SM>
 __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
     const u32x4 t = {v.x, v.y, v.z, v.w};
-    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)));
+    if (SM == SM_NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)));
+    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(t));
+    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(t));
     else *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)) = t;
 }
 __device__ __forceinline__ void store4(int8_t *dst, uint32_t v) { *reinterpret_cast<uint32_t *>(dst) = v; }

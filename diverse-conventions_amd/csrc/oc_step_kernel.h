@@ -17,11 +17,11 @@ __global__ __launch_bounds__(kWave) void oc_step_kernel(const StepArgs a) {
 }
 template <bool ACT64, bool VEC16, int QN>
 __global__ __launch_bounds__(kWave) void oc_rollout_kernel(const StepArgs a) {
-    generic::step_body<true, ACT64, VEC16, QN, false, true>(a, blockIdx.x, gridDim.x);
+    generic::step_body<true, ACT64, VEC16, QN, SM_PLAIN, true>(a, blockIdx.x, gridDim.x);
 }
 template <bool VEC16, int QN>
 __global__ __launch_bounds__(kWave) void oc_observe_batch_kernel(const StepArgs a) {
-    generic::step_body<false, false, VEC16, QN, false, false, true>(a, blockIdx.x, gridDim.x);
+    generic::step_body<false, false, VEC16, QN, SM_PLAIN, false, true>(a, blockIdx.x, gridDim.x);
 }
 
 }  // namespace oc_dev

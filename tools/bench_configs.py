@@ -86,6 +86,27 @@ def config3(n=8192, k=7, T=400):
     return out
 
 
+def config3_group(n=8192, T=400, kpw=None, passes=0, wpc=0, layouts=None):
+    """Config 3's env step as ONE launch per joint step (EngineGroup / oc_group_step): 5 classic layouts x 8192 kitchens."""
+    from diverse_conventions_amd import EngineGroup
+    layouts = list(layouts or CLASSIC_LAYOUTS)
+    grp = EngineGroup.from_layouts(layouts, n, 0)
+    if kpw or passes or wpc:
+        grp.set_tuning(kpw, passes, wpc)
+    acts = [torch.randint(0, 6, (64, 2, e.num_kitchens), device="cuda", dtype=torch.int32) for e in grp.engines]
+    grp.rollout_timed(acts, 50)
+    ms = min(grp.rollout_timed(acts, T) for _ in range(3))
+    us = ms * 1e3 / T
+    total_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
+    kitchens = sum(e.num_kitchens for e in grp.engines)
+    out = {"what": f"config 3 env step as ONE launch: {len(layouts)} layouts x {n} kitchens (oc_group_step)", "kitchens_total": kitchens,
+           "us_per_joint_step": round(us, 2), "agent_env_steps_per_s": round(2 * kitchens / us * 1e6),
+           "algorithmic_GBps": round(total_bytes / us / 1e3, 1), "roofline_frac": round(total_bytes / us / 1e3 / 8000, 3),
+           "bytes_per_launch": total_bytes, "build": grp.build_info}
+    grp.close(close_engines=True)
+    return out
+
+
 def config3_policies(n=8192, k=7, T=200, critics=True):
     """Config 3 with the policies in the loop: per layout 8 conventions' actors (+ one critic per segment and side) on
     the fused MFMA kernel + the env step, five layouts on five streams (the HBM-bound env kernel of one layout overlaps
@@ -126,6 +147,14 @@ def config3_policies(n=8192, k=7, T=200, critics=True):
 
 
 if __name__ == "__main__":
+    if "--group" in sys.argv:
+        print(json.dumps(config3()), flush=True)
+        print(json.dumps(config3_group()), flush=True)
+        print(json.dumps(config3_group(wpc=9)), flush=True)
+        print(json.dumps(config3_group(kpw=[32, 16, 24, 24, 16])), flush=True)
+        print(json.dumps(config3_group(passes=2)), flush=True)
+        print(json.dumps(config3_group(n=65536, T=100)), flush=True)
+        sys.exit(0)
     if "--policies" in sys.argv:
         print(json.dumps(config3_policies(critics=False)), flush=True)
         print(json.dumps(config3_policies(critics=True)), flush=True)
