@@ -126,7 +126,10 @@ def main():
         local = int(os.environ["OC_BENCH_DEVICE"])
     backend = os.environ.get("OC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    if world > 1:
+    # OC_BENCH_FORCE_DIST=1: run the process-group code (RCCL init, barriers, the MAX all-reduce) even with one rank, so
+    # that a 1-GPU box executes the nccl branch too
+    use_dist = world > 1 or bool(os.environ.get("OC_BENCH_FORCE_DIST"))
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -144,7 +147,7 @@ def main():
     actions = torch.randint(0, 6, (t_act, 2, n), generator=gen, device="cuda", dtype=torch.int32)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,16 +169,83 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     fused_ms = ev0.elapsed_time(ev1)
-    stats = torch.tensor([wall, kernel_ms, fused_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    # Secondary figure, never `value`: HBM proper.  The same K launches with every step's observations / rewards / dones
+    # written to their own time-major trajectory slot (what a rollout buffer wants): 64 slots x 52 MB are
+    # far beyond the 256 MB Infinity Cache, so no byte is absorbed on-die (the in-place buffer of `value` is the
+    # reference's data-plane contract -- the simulator's persistent output tensors, overwritten every step -- and fits it).
+    barrier()
+    slots = 64
+    tm_obs = torch.empty((slots,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+    tm_rew = torch.empty((slots, 2, n), dtype=torch.int32, device="cuda")
+    tm_done = torch.empty((slots, n), dtype=torch.int32, device="cuda")
+    eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
+    tm_rounds = max(1, min(args.steps, 640) // slots)
+    ev0.record()
+    for _ in range(tm_rounds):
+        eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
+    ev1.record()
+    torch.cuda.synchronize()
+    tm_us = ev0.elapsed_time(ev1) * 1e3 / (tm_rounds * slots)
+    del tm_obs, tm_rew, tm_done
+
+    # Secondary figure, never `value`: BASELINE config 4's split -- asymmetric_advantages, 65 536 kitchens in total, i.e.
+    # 65 536 / N per GPU (strong scaling; 8192 per GPU on the 8-GPU node the config names).
+    barrier()
+    c4_total = 65536
+    c4_n = c4_total // world
+    c4_params = get_base_layout_params("asymmetric_advantages", 200)
+    c4_S = c4_params["width"] * c4_params["height"]
+    eng4 = OvercookedEngine(c4_params, c4_n, local)
+    act4 = torch.randint(0, 6, (t_act, 2, c4_n), generator=gen, device="cuda", dtype=torch.int32)
+    c4_steps = min(args.steps, 1000)
+    eng4.rollout(act4, min(args.warmup, 100))
+    barrier()
+    t4 = time.perf_counter()
+    c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
+    barrier()
+    c4_wall = time.perf_counter() - t4
+    eng4.close()
+
+    # Secondary figure, never `value`: BASELINE config 3's env step -- the five classic layouts x 8192 kitchens stepped by
+    # ONE launch (oc_group_step)
+    c3 = None
+    if world == 1:
+        from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup
+        grp = EngineGroup.from_layouts(CLASSIC_LAYOUTS, 8192, local)
+        act3 = [torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32) for _ in grp.engines]
+        grp.rollout_timed(act3, 50)
+        c3_steps = min(args.steps, 1000)
+        c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
+        c3_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
+        c3 = {"what": "BASELINE config 3 env step: 5 classic layouts x 8192 kitchens, ONE launch per joint step (oc_group_step)",
+              "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
+              "bytes_per_launch": c3_bytes, "achieved_GBps": c3_bytes / c3_us / 1e3, "frac_of_8TBps": c3_bytes / c3_us / 1e3 / HBM_PEAK_GBS,
+              "build": grp.build_info}
+        grp.close(close_engines=True)
+
+    # every rank's timings -> the slowest rank's (MAX), as the contract asks for `value`
+    stats = torch.tensor([wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+    if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    wall, kernel_ms, fused_ms = float(stats[0]), float(stats[1]), float(stats[2])
+    wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms = (float(x) for x in stats)
     fused_bytes = n * (2 * S * 20 + 8 + 8 + 4)            # obs + i32 actions + reward + done; no state round trip
     fused = {"what": "same steps as one launch (state resident in LDS), action tape in HBM, outputs in place",
              "us_per_step": fused_ms * 1e3 / args.steps, "value": 2 * n * world * args.steps / (fused_ms / 1e3),
              "unit": "agent-env steps/s", "bytes_per_step": fused_bytes,
              "achieved_GBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9,
              "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+    hbm_proper = {"what": f"the headline workload with every step's outputs written to their own time-major slot ({slots} slots, "
+                          f"{slots * 2 * n * S * 20 / 1e9:.1f} GB: beyond the 256 MB Infinity Cache), one launch per step, non-temporal plane stores",
+                  "us_per_launch": tm_us, "value": 2 * n * world / tm_us * 1e6, "unit": "agent-env steps/s",
+                  "achieved_GBps": algorithmic_bytes(S) * n / tm_us / 1e3, "frac_of_8TBps": algorithmic_bytes(S) * n / tm_us / 1e3 / HBM_PEAK_GBS}
+    c4_us = c4_kernel_ms * 1e3 / c4_steps
+    config4_split = {"what": f"BASELINE config 4's split (strong scaling): asymmetric_advantages, {c4_total} kitchens in total = {c4_n} per GPU "
+                             f"on {world} GPU(s), one launch per step, outputs in place",
+                     "kitchens_per_gpu": c4_n, "us_per_launch": c4_us, "value": 2 * c4_n * world * c4_steps / c4_wall,
+                     "unit": "agent-env steps/s", "scaling": "strong",
+                     "achieved_GBps_per_gpu": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3,
+                     "frac_of_8TBps": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3 / HBM_PEAK_GBS}
 
     # Secondary figure, never `value`: policies in the loop.  8 conventions in the reference's 15 pairing
     # segments, every actor on both sides evaluated by ONE fused MFMA launch (oc_policy_forward) per step + the env launch;
@@ -230,13 +300,17 @@ def main():
         bytes_per_launch = algorithmic_bytes(S) * n
         per_launch_s = kernel_ms / 1e3 / args.steps
         achieved = bytes_per_launch / per_launch_s / 1e9
-        traffic = None
+        # HBM traffic per launch comes from PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of this very
+        # command, see profiles/README.md), not from this process: it is read from the committed summary and labelled so
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            key = f"{args.layout}:{n}"
-            traffic = tj.get(key, {}).get("bytes_per_launch")
+            entry = tj.get(f"{args.layout}:{n}", {})
+            traffic = entry.get("bytes_per_launch")
+            if traffic is not None:
+                traffic_source = f"profiles/hbm_traffic.json ({entry.get('measured', 'round unknown')}): {entry.get('source', '')}"
         out = {
             "metric": "agent-env steps/sec at 64k parallel kitchens, 1/2/4/8 MI355X",
             "value": 2 * n * world * args.steps / wall,
@@ -250,11 +324,15 @@ def main():
                                    f"one launch per step",
                        "layout": args.layout, "kitchens_per_gpu": n, "parallelism": f"kitchen-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "oc_jit_step_i32_v16" if "specialised" in build_info else "oc_step_kernel<STEP,i32,vec16>",
                          "kernel_build": build_info, "bytes_per_launch": bytes_per_launch,
                          "us_per_launch": per_launch_s * 1e6},
         }
+        out["hbm_proper"] = hbm_proper
+        out["config4_split"] = config4_split
+        if c3 is not None:
+            out["config3_one_launch"] = c3
         out["fused_rollout"] = fused
         if policy is not None:
             out["policy_in_loop"] = policy
@@ -262,7 +340,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params, n)
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

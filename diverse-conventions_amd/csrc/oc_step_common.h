@@ -231,7 +231,7 @@ __device__ __forceinline__ int sanitize_action(int a) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// one global_store_dwordx4 (VEC16 launches only).  SM = store mode of the observation planes:
+// one global_store_dwordx4 (VEC16 kernels).  SM = store mode of the observation planes:
 //   0 plain: the lines stay dirty in the XCD's L2 until evicted or until the end-of-kernel write-back;
 //   1 non-temporal, for destinations that are not rewritten soon (a fresh trajectory slot every step): measured 13.5
 //     vs 14.7 us per launch into a 10 GB time-major buffer, but 13.5 vs 13.2 us when the same 52 MB buffer is
@@ -242,14 +242,20 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The write-through forms have no builtin for 16-byte stores, hence the inline asm; nothing in the kernel reads what
 // these stores write, so the asm needs no memory clobber, and stores the compiler does not count only make its own
 // vmcnt waits more conservative (vmcnt retires in order).
-enum : int { SM_PLAIN = 0, SM_NT = 1, SM_SC1 = 2, SM_SC0SC1 = 3 };
+enum : int { SM_PLAIN = 0, SM_NT = 1, SM_SC1 = 2, SM_SC0SC1 = 3, SM_SC1_NT = 4 };
+// The destination is 16-byte aligned relative to its viewer plane, and a plane is only guaranteed 4-byte alignment (the
+// second viewer's plane of 8190 kitchens of a 5x5 grid starts 8 bytes off): gfx950 under ROCm runs compute queues in
+// unaligned-access mode, where a dwordx4 access needs dword alignment only -- measured 14.98 us per launch against 17.47 us
+// for the same batch written with dword stores (profiles/r02_misaligned_planes.log).
+typedef u32x4 __attribute__((aligned(4))) u32x4_dword_aligned;
 template <int SM>
 __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
     const u32x4 t = {v.x, v.y, v.z, v.w};
-    if (SM == SM_NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)));
+    if (SM == SM_NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4_dword_aligned *>(dst));
     else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(t));
     else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(t));
-    else *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(dst, 16)) = t;
+    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(t));
+    else *reinterpret_cast<u32x4_dword_aligned *>(dst) = t;
 }
 __device__ __forceinline__ void store4(int8_t *dst, uint32_t v) { *reinterpret_cast<uint32_t *>(dst) = v; }
 

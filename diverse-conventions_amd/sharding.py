@@ -75,16 +75,18 @@ class TrajectoryExchange:
     and hands back per-field views of the result, peers in rank order: [world, T, ...].  Shards must be equal-sized
     (use a kitchen count divisible by the world size); errors of the collective propagate."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, always_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.collectives = 0                      # all-gathers issued so far (one per gather_trajectory)
+        # a single rank needs no collective; always_collective issues it anyway (how a 1-GPU box exercises the RCCL call)
+        self.always_collective = bool(always_collective) and dist.is_initialized()
 
     def all_gather(self, local: torch.Tensor) -> torch.Tensor:
         """[...] -> [world, ...], rank r's tensor at index r."""
         local = local.contiguous()
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return local.unsqueeze(0)
         out = torch.empty((self.world * local.numel(),), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.view(-1), group=self.group)

@@ -153,8 +153,8 @@ int oc_encode_trajectory(oc_engine *e, const void *d_states, int64_t n, int64_t 
  * specialised kernel body per distinct layout and hands every engine a share of the persistent wavefronts in proportion to
  * its tiles, so the constant folding of the per-engine build is kept and the four extra launch boundaries are not paid.
  * The pointer tables are HOST arrays of oc_group_size() device pointers, in the order of oc_group_create; buffers, dtypes
- * and results per engine are exactly those of oc_step / oc_observe.  Without a usable hiprtc (or with obs buffers that are
- * not 16-byte aligned) the calls fall back to one launch per engine, same results (oc_group_build_info says which). */
+ * and results per engine are exactly those of oc_step / oc_observe.  Without a usable hiprtc the calls fall back to one
+ * launch per engine, same results (oc_group_build_info says which). */
 typedef struct oc_group oc_group;
 int oc_group_create(oc_engine *const *engines, int32_t n_engines, oc_group **out);
 int oc_group_destroy(oc_group *g);                    /* the engines stay alive and belong to the caller */

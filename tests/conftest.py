@@ -25,6 +25,53 @@ def pytest_configure(config):
     oracle.build()
 
 
+class CleanLauncher:
+    """Runs commands in a helper process that never touched the GPU (tests/_clean_launcher.py)."""
+
+    def __init__(self):
+        import subprocess
+        self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_clean_launcher.py")], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, cwd=ROOT)
+
+    def run(self, cmd, env=None, timeout=600):
+        self.proc.stdin.write(json.dumps({"cmd": list(cmd), "env": env or {}, "cwd": ROOT, "timeout": timeout}) + "\n")
+        self.proc.stdin.flush()
+        return json.loads(self.proc.stdout.readline())
+
+    def close(self):
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=10)
+        except Exception:
+            self.proc.kill()
+
+
+_launcher = None
+
+
+def pytest_sessionstart(session):
+    # Started here, before any test (or the collection hook below) initialises the GPU; counting devices does not.
+    global _launcher
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            _launcher = CleanLauncher()
+    except Exception:
+        _launcher = None
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _launcher is not None:
+        _launcher.close()
+
+
+@pytest.fixture(scope="session")
+def clean_launcher():
+    if _launcher is None:
+        pytest.skip("no GPU box: the clean launcher is only started there")
+    return _launcher
+
+
 def golden_files(prefix):
     return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
 

@@ -1,0 +1,51 @@
+"""bench.py's multi-rank path executed for real: two ranks launched exactly as the driver launches them
+(`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both pinned to the one GPU of the test box
+(OC_BENCH_DEVICE=0) with gloo as the control-plane backend (two NCCL ranks cannot share a device).  The rollout itself has
+no data-path collective, so this exercises everything but the backend name: rendezvous, barriers, MAX over ranks, the JSON."""
+import json
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_one_json_line(clean_launcher):
+    one = clean_launcher.run([sys.executable, "bench.py", "--steps", "300", "--warmup", "50", "--no-cpu-baseline", "--no-policy"], timeout=500)
+    assert one["rc"] == 0, one["stderr"][-2000:]
+    lines1 = [ln for ln in one["stdout"].splitlines() if ln.startswith("{")]
+    assert len(lines1) == 1
+    j1 = json.loads(lines1[0])
+    assert j1["n_gpus"] == 1 and j1["scaling"] == "weak" and j1["roofline"]["bound"] == "hbm"
+    two = clean_launcher.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "300", "--warmup", "50"],
+                             env={"OC_BENCH_DEVICE": "0", "OC_BENCH_BACKEND": "gloo"}, timeout=500)
+    assert two["rc"] == 0, two["stderr"][-2000:]
+    lines2 = [ln for ln in two["stdout"].splitlines() if ln.startswith("{")]
+    assert len(lines2) == 1, "rank 0 prints exactly one JSON line"
+    j2 = json.loads(lines2[0])
+    assert j2["n_gpus"] == 2 and j2["steps"] == 300 and j2["warmup"] == 50 and j2["metric"] == j1["metric"]
+    assert j2["config"]["kitchens_per_gpu"] == 65536 and "x2" in j2["config"]["parallelism"]
+    # whole-job throughput: twice the kitchens in (two ranks time-sharing one GPU) about twice the time; the value must be
+    # computed from all ranks' kitchens and the slowest rank's time, so it lands near the single-rank figure, not at half or double
+    assert 0.6 * j1["value"] < j2["value"] < 1.4 * j1["value"], (j1["value"], j2["value"])
+    assert abs(j2["value"] - 2 * 65536 * 2 * 300 / (j2["ms_per_step"] * 300 / 1e3)) < 1e-3 * j2["value"]
+    # the strong-scaling secondary: config 4's split is 65 536 / world kitchens per GPU
+    assert j1["config4_split"]["kitchens_per_gpu"] == 65536 and j2["config4_split"]["kitchens_per_gpu"] == 32768
+    assert "cpu_baseline" not in j2 and "hbm_proper" in j2
+
+
+def test_rccl_branch_runs_with_one_rank(clean_launcher):
+    """The `nccl` (= RCCL) branches -- never taken by the gloo tests -- with a single rank on the box's one GPU: bench.py's
+    process-group path, and the packed trajectory all-gather / score all-reduce of sharding.py as real RCCL calls."""
+    run = lambda extra, env, port: clean_launcher.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port)] + extra, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=400)
+    b = run(["bench.py", "--gpus", "1", "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-policy"], {"OC_BENCH_FORCE_DIST": "1"}, 29543)
+    assert b["rc"] == 0, b["stderr"][-2000:]
+    j = json.loads([ln for ln in b["stdout"].splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["value"] > 1e9
+    r = run(["tests/_rccl_single_rank.py"], {}, 29545)
+    assert r["rc"] == 0, r["stderr"][-2000:]
+    out = json.loads([ln for ln in r["stdout"].splitlines() if ln.startswith("{")][0])
+    assert out == {"ok": True, "backend": "nccl", "world": 1, "collectives": 1}

@@ -113,15 +113,17 @@ def test_group_step_is_one_launch_bit_exact_vs_oracle(layout_params):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["default", "int64", "tuned", "nine_waves", "no_jit", "time_major", "misaligned"])
+@pytest.mark.parametrize("mode", ["default", "int64", "tuned", "nine_waves", "no_jit", "time_major", "misaligned", "dword_stores"])
 def test_group_equals_engines_stepped_one_by_one(mode, layout_params, monkeypatch):
     """Whatever the configuration -- action dtype, launch geometry, the per-engine fallback, fresh destination slots
-    (non-temporal stores), obs buffers that are not 16-byte aligned -- a group step leaves exactly what stepping its
-    engines one after the other leaves."""
+    (non-temporal stores), obs buffers that are only 4-byte aligned, the dword-store diagnostics -- a group step leaves
+    exactly what stepping its engines one after the other leaves."""
     from diverse_conventions_amd import EngineGroup, OvercookedEngine
     names, counts, T = ["random3", "simple", "simple", "random0"], [300, 257, 64, 411], 40
     if mode == "no_jit":
         monkeypatch.setenv("OC_NO_JIT", "1")
+    if mode == "dword_stores":
+        monkeypatch.setenv("OC_DWORD_STORES", "1")
     params = [layout_params[n] for n in names]
     solo = [OvercookedEngine(p, n, 0) for p, n in zip(params, counts)]
     engines = [OvercookedEngine(p, n, 0) for p, n in zip(params, counts)]

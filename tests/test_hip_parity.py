@@ -165,24 +165,29 @@ def test_small_and_ragged_sizes(n, layout_params, monkeypatch):
         eng.close()
 
 
-def test_unaligned_destination_and_int64_actions(layout_params):
-    """obs written into a caller buffer that is only 4-byte aligned (dword store path), actions as
-    int64 [P, N, 1] exactly as torch.stack of sampled actions gives them."""
+@pytest.mark.parametrize("stores", ["wide", "dword"])
+@pytest.mark.parametrize("offset", [4, 8, 12])
+def test_unaligned_destination_and_int64_actions(stores, offset, layout_params, monkeypatch):
+    """obs written into a caller buffer that is only 4-byte aligned -- 16-byte stores on dword-aligned addresses, the
+    default, and the dword-store kernels (OC_DWORD_STORES=1) -- with canary bytes on both sides; actions as int64
+    [P, N, 1] exactly as torch.stack of sampled actions gives them."""
+    if stores == "dword":
+        monkeypatch.setenv("OC_DWORD_STORES", "1")
     params = layout_params["simple"]
     n, T = 515, 60
     acts = _mixed_actions("simple", T, n, seed=2)
     ora = oracle.OracleVecEnv(params, n)
     eng = _engine(params, n)
     raw = torch.zeros(eng.obs.numel() + 64, dtype=torch.int8, device="cuda")
-    view = raw[4:4 + eng.obs.numel()].view(eng.obs.shape)
-    assert view.data_ptr() % 16 == 4
+    view = raw[offset:offset + eng.obs.numel()].view(eng.obs.shape)
+    assert view.data_ptr() % 16 == offset
     for t in range(T):
         a64 = torch.from_numpy(acts[t]).cuda().to(torch.int64).unsqueeze(-1)
         obs, rew, done = eng.step(a64, obs=view)
         oobs, orew, odone = ora.step(acts[t])
         assert np.array_equal(obs.cpu().numpy(), oobs), t
         assert np.array_equal(rew.cpu().numpy(), orew)
-    assert int(raw[:4].abs().sum()) == 0 and int(raw[4 + eng.obs.numel():].abs().sum()) == 0   # no stray writes
+    assert int(raw[:offset].abs().sum()) == 0 and int(raw[offset + eng.obs.numel():].abs().sum()) == 0   # no stray writes
     eng.close()
 
 
