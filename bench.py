@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="staging passes per flush (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-policy", action="store_true", help="skip the policies-in-the-loop secondary figure")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline measurement only (profiling runs: every launch of the step kernel is then the headline workload's)")
     args = ap.parse_args()
 
     import torch
@@ -157,71 +159,74 @@ def main():
     kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
     barrier()
     wall = time.perf_counter() - t0
-    # Secondary figure, never `value`: the same K steps as ONE launch (oc_rollout_fused: per-kitchen state stays in
-    # LDS between steps, same action tape read from HBM every step, every step's obs/reward/done written).
-    # Only usable when actions are known ahead, which is exactly this synthetic rollout; a policy in the loop
-    # needs the one-launch-per-step path that `value` measures.
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    eng.rollout_fused(min(args.steps, 200), actions=actions)
-    ev0.record()
-    eng.rollout_fused(args.steps, actions=actions)
-    ev1.record()
-    torch.cuda.synchronize()
-    fused_ms = ev0.elapsed_time(ev1)
-    # Secondary figure, never `value`: HBM proper.  The same K launches with every step's observations / rewards / dones
-    # written to their own time-major trajectory slot (what a rollout buffer wants): 64 slots x 52 MB are
-    # far beyond the 256 MB Infinity Cache, so no byte is absorbed on-die (the in-place buffer of `value` is the
-    # reference's data-plane contract -- the simulator's persistent output tensors, overwritten every step -- and fits it).
-    barrier()
-    slots = 64
-    tm_obs = torch.empty((slots,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
-    tm_rew = torch.empty((slots, 2, n), dtype=torch.int32, device="cuda")
-    tm_done = torch.empty((slots, n), dtype=torch.int32, device="cuda")
-    eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
-    tm_rounds = max(1, min(args.steps, 640) // slots)
-    ev0.record()
-    for _ in range(tm_rounds):
+    fused_ms = tm_us = c4_wall = c4_kernel_ms = float("nan")
+    slots, c4_total, c4_n, c4_S, c4_steps, c3 = 64, 65536, 65536 // world, 45, 1, None
+    if not args.no_secondary:
+        # Secondary figure, never `value`: the same K steps as ONE launch (oc_rollout_fused: per-kitchen state stays in
+        # LDS between steps, same action tape read from HBM every step, every step's obs/reward/done written).
+        # Only usable when actions are known ahead, which is exactly this synthetic rollout; a policy in the loop
+        # needs the one-launch-per-step path that `value` measures.
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng.rollout_fused(min(args.steps, 200), actions=actions)
+        ev0.record()
+        eng.rollout_fused(args.steps, actions=actions)
+        ev1.record()
+        torch.cuda.synchronize()
+        fused_ms = ev0.elapsed_time(ev1)
+        # Secondary figure, never `value`: HBM proper.  The same K launches with every step's observations / rewards / dones
+        # written to their own time-major trajectory slot (what a rollout buffer wants): 64 slots x 52 MB are
+        # far beyond the 256 MB Infinity Cache, so no byte is absorbed on-die (the in-place buffer of `value` is the
+        # reference's data-plane contract -- the simulator's persistent output tensors, overwritten every step -- and fits it).
+        barrier()
+        slots = 64
+        tm_obs = torch.empty((slots,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+        tm_rew = torch.empty((slots, 2, n), dtype=torch.int32, device="cuda")
+        tm_done = torch.empty((slots, n), dtype=torch.int32, device="cuda")
         eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
-    ev1.record()
-    torch.cuda.synchronize()
-    tm_us = ev0.elapsed_time(ev1) * 1e3 / (tm_rounds * slots)
-    del tm_obs, tm_rew, tm_done
+        tm_rounds = max(1, min(args.steps, 640) // slots)
+        ev0.record()
+        for _ in range(tm_rounds):
+            eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
+        ev1.record()
+        torch.cuda.synchronize()
+        tm_us = ev0.elapsed_time(ev1) * 1e3 / (tm_rounds * slots)
+        del tm_obs, tm_rew, tm_done
 
-    # Secondary figure, never `value`: BASELINE config 4's split -- asymmetric_advantages, 65 536 kitchens in total, i.e.
-    # 65 536 / N per GPU (strong scaling; 8192 per GPU on the 8-GPU node the config names).
-    barrier()
-    c4_total = 65536
-    c4_n = c4_total // world
-    c4_params = get_base_layout_params("asymmetric_advantages", 200)
-    c4_S = c4_params["width"] * c4_params["height"]
-    eng4 = OvercookedEngine(c4_params, c4_n, local)
-    act4 = torch.randint(0, 6, (t_act, 2, c4_n), generator=gen, device="cuda", dtype=torch.int32)
-    c4_steps = min(args.steps, 1000)
-    eng4.rollout(act4, min(args.warmup, 100))
-    barrier()
-    t4 = time.perf_counter()
-    c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
-    barrier()
-    c4_wall = time.perf_counter() - t4
-    eng4.close()
+        # Secondary figure, never `value`: BASELINE config 4's split -- asymmetric_advantages, 65 536 kitchens in total, i.e.
+        # 65 536 / N per GPU (strong scaling; 8192 per GPU on the 8-GPU node the config names).
+        barrier()
+        c4_total = 65536
+        c4_n = c4_total // world
+        c4_params = get_base_layout_params("asymmetric_advantages", 200)
+        c4_S = c4_params["width"] * c4_params["height"]
+        eng4 = OvercookedEngine(c4_params, c4_n, local)
+        act4 = torch.randint(0, 6, (t_act, 2, c4_n), generator=gen, device="cuda", dtype=torch.int32)
+        c4_steps = min(args.steps, 1000)
+        eng4.rollout(act4, min(args.warmup, 100))
+        barrier()
+        t4 = time.perf_counter()
+        c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
+        barrier()
+        c4_wall = time.perf_counter() - t4
+        eng4.close()
 
-    # Secondary figure, never `value`: BASELINE config 3's env step -- the five classic layouts x 8192 kitchens stepped by
-    # ONE launch (oc_group_step)
-    c3 = None
-    if world == 1:
-        from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup
-        grp = EngineGroup.from_layouts(CLASSIC_LAYOUTS, 8192, local)
-        act3 = [torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32) for _ in grp.engines]
-        grp.rollout_timed(act3, 50)
-        c3_steps = min(args.steps, 1000)
-        c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
-        c3_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
-        c3 = {"what": "BASELINE config 3 env step: 5 classic layouts x 8192 kitchens, ONE launch per joint step (oc_group_step)",
-              "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
-              "bytes_per_launch": c3_bytes, "achieved_GBps": c3_bytes / c3_us / 1e3, "frac_of_8TBps": c3_bytes / c3_us / 1e3 / HBM_PEAK_GBS,
-              "build": grp.build_info}
-        grp.close(close_engines=True)
+        # Secondary figure, never `value`: BASELINE config 3's env step -- the five classic layouts x 8192 kitchens stepped by
+        # ONE launch (oc_group_step)
+        c3 = None
+        if world == 1:
+            from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup
+            grp = EngineGroup.from_layouts(CLASSIC_LAYOUTS, 8192, local)
+            act3 = [torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32) for _ in grp.engines]
+            grp.rollout_timed(act3, 50)
+            c3_steps = min(args.steps, 1000)
+            c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
+            c3_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
+            c3 = {"what": "BASELINE config 3 env step: 5 classic layouts x 8192 kitchens, ONE launch per joint step (oc_group_step)",
+                  "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
+                  "bytes_per_launch": c3_bytes, "achieved_GBps": c3_bytes / c3_us / 1e3, "frac_of_8TBps": c3_bytes / c3_us / 1e3 / HBM_PEAK_GBS,
+                  "build": grp.build_info}
+            grp.close(close_engines=True)
 
     # every rank's timings -> the slowest rank's (MAX), as the contract asks for `value`
     stats = torch.tensor([wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms], dtype=torch.float64,
@@ -251,7 +256,7 @@ def main():
     # segments, every actor on both sides evaluated by ONE fused MFMA launch (oc_policy_forward) per step + the env launch;
     # random-weight networks of the reference shape; own engine because 15 segments do not divide 65 536.
     policy = None
-    if world == 1 and not args.no_policy and params["width"] * params["height"] <= 63:
+    if world == 1 and not args.no_policy and not args.no_secondary and params["width"] * params["height"] <= 63:
       try:                                                 # a secondary figure must never take the headline line down with it
           from diverse_conventions_amd import FusedPairedRollout, PackedNetworks
           k = 7
@@ -329,11 +334,12 @@ def main():
                          "kernel_build": build_info, "bytes_per_launch": bytes_per_launch,
                          "us_per_launch": per_launch_s * 1e6},
         }
-        out["hbm_proper"] = hbm_proper
-        out["config4_split"] = config4_split
-        if c3 is not None:
-            out["config3_one_launch"] = c3
-        out["fused_rollout"] = fused
+        if not args.no_secondary:
+            out["hbm_proper"] = hbm_proper
+            out["config4_split"] = config4_split
+            if c3 is not None:
+                out["config3_one_launch"] = c3
+            out["fused_rollout"] = fused
         if policy is not None:
             out["policy_in_loop"] = policy
         if world == 1 and not args.no_cpu_baseline:

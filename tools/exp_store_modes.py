@@ -50,7 +50,7 @@ def group(n, steps):
     return round(us, 2), round(b / us / 1e3 / 8000, 3)
 
 
-for mode in ("0,1", "2,1", "2,2"):
+for mode in (sys.argv[1:] or ["0,1", "2,1", "2,2"]):
     os.environ["OC_STORE_MODE"] = mode
     out = {"mode(in_place,fresh)": mode,
            "cramped 65536 in place": single("cramped_room", 65536, 1000),
