@@ -292,10 +292,20 @@ class OvercookedEngine:
             raise ValueError("checkpoint was taken from an engine of another size")
         if any(sd["layout"][k] != (list(v) if isinstance(v, (list, tuple)) else v) for k, v in self.params.items()):
             raise ValueError("checkpoint was taken from another layout")
-        rec = sd["records"].contiguous()
-        tiles, players, ts = unpack_states(rec.numpy().view(np.uint32), self.size)
-        self.set_state(tiles, players, ts)              # host path: validates player positions before upload
+        # device path: one upload, one checking kernel (oc_import_states_checked), one scalar read-back
+        rec = sd["records"].contiguous().to(self.device, dtype=torch.int32)
+        rejected = self.import_states_checked(rec)
+        if rejected:
+            raise native.OvercookedNativeError(-1, f"{rejected} checkpoint record(s) have a player off the interior grid, a bad "
+                                                   "orientation or an unknown object code; nothing of them was loaded")
         self.observe()
+
+    def import_states_checked(self, records, first=0) -> int:
+        """Device-to-device import with a per-record validity check; returns the number of rejected (not copied) records."""
+        count = records.numel() * records.element_size() // self.record_bytes
+        rejected = torch.zeros(1, dtype=torch.int32, device=self.device)
+        native.check(self._L.oc_import_states_checked(self._handle, first, count, _ptr(records), _ptr(rejected), self._stream()))
+        return int(rejected.item())
 
     def get_state(self, first=0, count=None):
         """-> (tiles int8 [n,S,4], players int8 [n,2,6], timestep int32 [n]); synchronises."""

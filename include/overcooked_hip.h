@@ -178,6 +178,10 @@ int oc_get_state(oc_engine *e, int64_t first, int64_t count, void *host_dst);
 int oc_set_state(oc_engine *e, int64_t first, int64_t count, const void *host_src);
 int oc_export_states(oc_engine *e, int64_t first, int64_t count, void *d_dst, void *stream);
 int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_src, void *stream);
+/* The same with a device-side check of every record (players on interior tiles with orientations 0..3, object names
+ * 0..4 on tiles and in hands -- everything the kernels index with): records that fail are NOT copied and are counted in
+ * *d_rejected (device int32, zeroed by the call).  Checkpoint reload of a whole engine without a host pass. */
+int oc_import_states_checked(oc_engine *e, int64_t first, int64_t count, const void *d_src, int32_t *d_rejected, void *stream);
 
 /* ---- runner-side ops ---------------------------------------------------------------
  * Generalised advantage estimation over a whole trajectory batch in one launch; replaces the GAE branches

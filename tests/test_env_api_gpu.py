@@ -115,3 +115,35 @@ def test_fused_partner_agent_in_the_reference_loop(layout_params):
         oobs, orew, odone = ora.step(joint)
         assert np.array_equal(vobs.obs.cpu().numpy(), oobs[0]) and np.array_equal(rew.cpu().numpy(), orew[0])
     env.close()
+
+
+def test_the_simulator_stub_shown_in_integration_md_runs(layout_params):
+    """INTEGRATION.md section 2 is the ctypes stand-in for the reference's nanobind module
+    (build.madrona_simplecooked_example_python.SimplecookedSimulator, src/overcooked2_env/bindings.cpp:22-98): execute that
+    block as written and drive it the way OvercookedMadrona does -- write the actions in place, step(), read obs / reward /
+    done from the same persistent tensors (envs/overcooked2_env.py:116-125) -- against the oracle."""
+    import os
+    import re
+    from conftest import ROOT
+    from diverse_conventions_amd import native
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n# envs/overcooked_hip_binding\.py\n(.*?)```", text, re.S).group(1)
+    block = block.replace('"diverse-conventions_amd/csrc/liboc_hip.so"', repr(native.LIB_PATH))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:2", "exec"), ns)
+    params = layout_params["random1"]
+    n, T = 300, 205
+    kw = {k: params[k] for k in ("terrain", "height", "width", "num_players", "start_player_x", "start_player_y", "placement_in_pot_rew",
+                                 "dish_pickup_rew", "soup_pickup_rew", "recipe_values", "recipe_times", "horizon")}
+    sim = ns["SimplecookedSimulator"](exec_mode=None, gpu_id=0, num_worlds=n, debug_compile=False, **kw)     # bindings.cpp:28-84
+    ora = oracle.OracleVecEnv(params, n)
+    assert np.array_equal(sim.obs.cpu().numpy(), ora.encode())
+    rng = np.random.default_rng(4)
+    acts = rng.integers(0, 6, size=(T, 2, n, 1)).astype(np.int32)
+    for t in range(T):
+        sim.actions.copy_(torch.from_numpy(acts[t]).cuda())          # static_actions.copy_(...), overcooked2_env.py:119
+        sim.step()                                                   # self.sim.step(), :121
+        oobs, orew, odone = ora.step(acts[t][:, :, 0])
+        assert np.array_equal(sim.obs.cpu().numpy(), oobs), t
+        assert np.array_equal(sim.reward.cpu().numpy(), orew) and np.array_equal(sim.done.cpu().numpy(), odone)
+    assert int(ora.timestep[0]) == T - 200                           # the horizon reset happened inside step 200

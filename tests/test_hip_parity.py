@@ -428,7 +428,25 @@ def test_env_checkpoint_roundtrip(layout_params, tmp_path):
     other = _engine(layout_params["simple"], n)
     with pytest.raises(ValueError):
         other.load_state_dict(a.state_dict())
-    for e in (a, b, other):
+    # corrupted checkpoints are refused on the device (oc_import_states_checked): the damaged records are counted and not
+    # loaded, every other record is
+    from diverse_conventions_amd.native import OvercookedNativeError
+    sd = a.state_dict()
+    good = sd["records"].clone()
+    S = 40
+    sd["records"][5, S] = 0                        # player 0 on tile 0: a wall
+    sd["records"][9, S] = int(good[9, S]) | (7 << 8)          # orientation 7
+    sd["records"][200, 3] = 9                      # object code 9 on a tile
+    sd["records"][201, S + 1] = 77                 # ... and in a hand
+    c = _engine(params, n)
+    before = c.export_states().clone()
+    with pytest.raises(OvercookedNativeError, match="4 checkpoint record"):
+        c.load_state_dict(sd)
+    after = c.export_states().cpu()
+    bad = [5, 9, 200, 201]
+    keep = np.setdiff1d(np.arange(n), bad)
+    assert torch.equal(after[bad], before.cpu()[bad]) and torch.equal(after[keep], good[keep].to(torch.int32))
+    for e in (a, b, other, c):
         e.close()
 
 
@@ -449,3 +467,34 @@ def test_create_destroy_does_not_leak(layout_params):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 2**20, (free0, free1)
+
+
+def test_hip_replays_the_reference_syncvectorenv_recording(layout_params):
+    """The HIP engine directly against tests/golden/syncvec_simple.npz -- the reference's own SyncVectorEnv
+    (pantheonrl_extension/vectorenv.py:362-396) over 3 envs for 420 steps: the batched surface with its auto-reset rule
+    (terminal reward and done kept, the reset observation returned), six resets in the recording.  Also through the
+    drop-in class, whose ego view must be the recording's player-0 rows."""
+    from diverse_conventions_amd import OvercookedMadrona, RandomVectorAgent
+    rec = load_golden(os.path.join(GOLDEN, "syncvec_simple.npz"))
+    T = rec["actions"].shape[0]
+    eng = _engine(layout_params["simple"], 3)
+    assert np.array_equal(eng.observe().cpu().numpy(), rec["init_obs"])
+    acts = torch.from_numpy(rec["actions"].astype(np.int32)).cuda()
+    for t in range(T):
+        obs, rew, done = eng.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy(), rec["obs"][t]), t
+        assert np.array_equal(rew.cpu().numpy(), rec["reward"][t]), t
+        assert np.array_equal(done.cpu().numpy().astype(np.uint8), rec["done"][t]), t
+    eng.close()
+    assert rec["done"].sum() == 6
+    env = OvercookedMadrona("simple", 3, 0, debug_compile=False)
+    step_no = [0]
+    env.add_partner_agent(RandomVectorAgent(lambda: acts[step_no[0], 1].unsqueeze(-1)))
+    vobs = env.reset()
+    assert np.array_equal(vobs.obs.cpu().numpy(), rec["init_obs"][0])
+    for t in range(T):
+        step_no[0] = t
+        vobs, rew, done, _ = env.step(acts[t, 0].unsqueeze(-1))
+        assert np.array_equal(vobs.obs.cpu().numpy(), rec["obs"][t][0]), t
+        assert np.array_equal(rew.cpu().numpy(), rec["reward"][t][0]) and np.array_equal(done.cpu().numpy().astype(np.uint8), rec["done"][t])
+    env.close()
