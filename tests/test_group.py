@@ -229,9 +229,11 @@ def test_the_group_binding_shown_in_integration_md_runs(layout_params):
     from diverse_conventions_amd import native
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     ns = {}
-    for name in ("envs/overcooked_hip_binding.py", "envs/overcooked_hip_group.py"):
+    for name in ("envs/overcooked_hip_binding.py", "envs/overcooked_hip_group.py"):          # two files -> two module namespaces
         block = re.search(r"```python\n# " + re.escape(name) + r"\n(.*?)```", text, re.S).group(1)
-        exec(compile(block.replace('"diverse-conventions_amd/csrc/liboc_hip.so"', repr(native.LIB_PATH)), "INTEGRATION.md:" + name, "exec"), ns)
+        mod = {}
+        exec(compile(block.replace('"diverse-conventions_amd/csrc/liboc_hip.so"', repr(native.LIB_PATH)), "INTEGRATION.md:" + name, "exec"), mod)
+        ns.update({k: v for k, v in mod.items() if k in ("SimplecookedSimulator", "SimulatorGroup")})
     keys = ("terrain", "height", "width", "num_players", "start_player_x", "start_player_y", "placement_in_pot_rew", "dish_pickup_rew",
             "soup_pickup_rew", "recipe_values", "recipe_times", "horizon")
     make = lambda nm, n: ns["SimplecookedSimulator"](exec_mode=None, gpu_id=0, num_worlds=n, debug_compile=False, **{k: layout_params[nm][k] for k in keys})

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Policy kernel on the grids whose staging areas limit LDS to four (asymmetric_advantages, counter_circuit, the 5x5
+layouts): the pair plan (two wavefronts per SIMD sharing one staged block, oc_policy_pair_kernel) against the
+one-wavefront-per-SIMD plan.  OC_POLICY_PLAN is read once per process: run once with OC_POLICY_PLAN=nopair, once without.
+Prints per layout the policy launch alone (actors + critics, both sides) and the whole step of config 4's per-GPU share."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench_paired_rollout import random_actor, random_critic, run_fused
+from diverse_conventions_amd import get_base_layout_params
+from diverse_conventions_amd.fused_policy import TILE_ACT, PackedNetworks, PolicyPlan
+
+plan = os.environ.get("OC_POLICY_PLAN", "default")
+for layout, n in (("asymmetric_advantages", 30720), ("counter_circuit", 30720), ("forced_coordination", 61440), ("coordination_ring", 61440)):
+    params = get_base_layout_params(layout, 200)
+    W, H = params["width"], params["height"]
+    P = (W - 2) * (H - 2)
+    gen = torch.Generator().manual_seed(0)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_actor(W, H, gen=gen) for _ in range(4)],
+                                           critics=[random_critic(W, H, gen) for _ in range(4)])
+    rows = 2 * n
+    seg = rows // 4
+    segs = [(i * seg, seg, i, TILE_ACT) for i in range(4)] + [(i * seg, seg, 4 + i, 0) for i in range(4)]
+    pp = PolicyPlan(nets, rows, segs)
+    obs = (torch.rand((rows, W, H, 20), device="cuda") < 0.1).to(torch.int8)
+    acts = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    lp = torch.zeros(rows, device="cuda")
+    val = torch.zeros(rows, device="cuda")
+    for _ in range(5):
+        pp.forward(obs, raw=val, actions=acts, action_logp=lp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        pp.forward(obs, raw=val, actions=acts, action_logp=lp)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    evals = 2 * rows
+    cycles = evals / 32 * (P * (6 * 4 * 32 + 32 * 64) + 64 * 64 + 32 * 64)
+    bound24 = cycles / 1024 / 2400.0
+    print(json.dumps({"plan": plan, "layout": layout, "evaluations": evals, "us": round(us, 1), "issue_bound_us_at_2.4GHz": round(bound24, 1),
+                      "frac_of_bound_2.4GHz": round(bound24 / us, 3), "frac_at_2.1GHz": round(bound24 * 2.4 / 2.1 / us, 3)}), flush=True)
+r = run_fused("asymmetric_advantages", 8192 // 31, 15, critics=True)
+print(json.dumps({"plan": plan, "config4_share": r}), flush=True)
