@@ -1050,7 +1050,11 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
     // and split each block's conv positions; LDS = conv digits + [b1 | fc2 | b2] + 4 pair areas (fc1 and head from L2)
     const long long w_pair_tail = a.L.off_head - a.L.off_b1;
     const long long pair_area = std::max<long long>(a.lds_wave_bytes, (kPairExchangeBytes + 15) / 16 * 16);
-    bool pair = waves == 4 && a.L.P >= 2 && w_conv + w_pair_tail + 4 * pair_area <= kLds;
+    // Measured (profiles/r02_policy_pair_split.log): correct, but SLOWER than one wavefront per SIMD -- asymmetric_advantages
+    // 205 vs 176 us for 122 880 evaluations, config 4's per-GPU share 114 vs 93 us per step: five workgroup barriers per
+    // block and both roles reaching the exchanges together cost more than the interleaving of the position loops gains.
+    // Kept selectable (OC_POLICY_PLAN=pair) and tested; not the default.
+    bool pair = false;
     static const char *const env_plan = getenv("OC_POLICY_PLAN");     // diagnostics: "waves,fc1_lds,conv_lds" or "pair" / "nopair"
     if (env_plan) {
         int w = 0, f = 0, c = 0;
