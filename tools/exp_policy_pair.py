@@ -11,7 +11,7 @@ from diverse_conventions_amd import get_base_layout_params
 from diverse_conventions_amd.fused_policy import TILE_ACT, PackedNetworks, PolicyPlan
 
 plan = os.environ.get("OC_POLICY_PLAN", "default")
-for layout, n in (("asymmetric_advantages", 30720), ("counter_circuit", 30720), ("forced_coordination", 61440), ("coordination_ring", 61440)):
+for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("counter_circuit", 30720), ("forced_coordination", 61440), ("coordination_ring", 61440)):
     params = get_base_layout_params(layout, 200)
     W, H = params["width"], params["height"]
     P = (W - 2) * (H - 2)
