@@ -527,680 +527,6 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Pair kernel: for grids whose 32-row staging areas leave LDS room for only four of them (every classic layout but
-// cramped_room), two wavefronts of one SIMD share ONE staged block instead of each owning one -- so the SIMD still has
-// two wavefronts to interleave (one's LDS reads, operand conversion and epilogue under the other's MFMAs) at the LDS
-// footprint of four.  Wavefront w and w + 4 (same SIMD: waves of a workgroup go round the four SIMDs) are a pair:
-//   * conv positions are split even / odd between the two roles; each accumulates its own fc1 partial sums (the bias
-//     starts in role 0);
-//   * the dense layers are split the same way -- role r finalises h1 half r after receiving the partner's partial of
-//     it, multiplies it into partials of both h2 halves, finalises h2 half r, multiplies it into a partial of the head --
-//     with three exchanges through the (by then free) staging area; role 0 runs the epilogue;
-//   * MFMA work per block is exactly that of the one-wavefront kernel; sums are taken in a different order
-//     ((bias + even positions) + odd positions), within the same tolerances of the reference's f32 forward.
-// LDS: conv digits + [b1 | fc2 | b2]; fc1 and the head stream from L2 (each role needs only half of the head).
-constexpr int kPairExchangeBytes = 2 * 8192 + 1024;     // the pair area must hold exchange buffers A and B (+ slack)
-
-__device__ __forceinline__ void stage_rows_split(const PolicyArgs &a, uint8_t *ldsp, long long brow, int lane, int role) {
-    const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
-    const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
-    if (base + 16ll * n16 <= obs_bytes) {                             // whole block inside the tensor (wave-uniform)
-        const int8_t *src = a.obs + base + 16 * lane;
-        int it = role;                                                // role 0: 1-KiB pieces 0, 2, 4 ...; role 1: 1, 3, 5 ...
-        for (; (it + 1) * 64 <= n16; it += 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsp + it * 1024), 16, 0, 0);
-        if (it * 64 < n16 && it * 64 + lane < n16)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsp + it * 1024), 16, 0, 0);
-        return;
-    }
-    for (int it = role; it * 64 < n16; it += 2) {
-        const int i = it * 64 + lane;
-        const long long off = base + 16ll * i;
-        if (i < n16 && off + 16 <= obs_bytes) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.obs + off), (lptr_t)(ldsp + it * 1024), 16, 0, 0);
-        } else if (i < n16 && off < obs_bytes) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (off + 4 * q + 4 <= obs_bytes)
-                    reinterpret_cast<uint32_t *>(ldsp + 16 * i)[q] = *reinterpret_cast<const uint32_t *>(a.obs + off + 4 * q);
-        }
-    }
-}
-
-template <int NDIG>
-__global__ __launch_bounds__(512) void oc_policy_pair_kernel(const PolicyArgs a) {
-    extern __shared__ uint4 lds_raw[];
-    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave & 3, role = wave >> 2;
-    const int col = lane & 31, h = lane >> 5;
-    uint8_t *ldsp = lds + a.lds_weight_bytes + static_cast<size_t>(pair) * a.lds_wave_bytes;     // the pair's staging / exchange area
-    uint8_t *bufA = ldsp, *bufB = ldsp + 8192;
-
-    // ---- work distribution: as in oc_policy_kernel (one stretch of 32-row blocks per workgroup)
-    auto tile_blocks = [&](const int4 t) -> int { return policy_tile_blocks(a, t); };
-    long long wg0, wg1, tstart;
-    int ti;
-    if (!policy_find_stretch(a, lane, wg0, wg1, ti, tstart)) return;
-
-    const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
-    const uint32_t counter = a.counter + (a.counter_ptr ? *a.counter_ptr : 0u);
-    const int wstart = static_cast<int>(a.L.off_b1);                                  // image offset of the LDS tail [b1 | fc2 | b2]
-    const int conv_bytes = static_cast<int>(a.L.off_fc1 - a.L.off_conv);
-    uint8_t *lds_tail = lds + conv_bytes;
-    const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
-    const float *sbl = reinterpret_cast<const float *>(lds + (a.L.off_conv_sb - a.L.off_conv)) + h * 16;
-    const float *b1 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b1 - wstart)) + h * 16;
-    const v4f *w2 = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
-    const float *b2 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b2 - wstart)) + h * 16;
-    const v4f *w1g = nullptr, *whg = nullptr;
-    const float *bhg = nullptr;
-    const uint8_t *rowp = ldsp + col * RB + 16 * h;
-    const int colstep = H * OC_POLICY_C;
-    const int n_pos = (P - role + 1) / 2;                                             // positions role, role + 2, ...
-    int loaded_net = -1, n_out = 1;
-
-    auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
-        float t;
-        if (NDIG == 1) t = static_cast<float>(acc[0][r]);
-        else {
-            t = static_cast<float>(acc[0][r] * 128 + acc[1][r]);
-            if (NDIG == 3) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[2][r]));
-            if (NDIG == 4) t = __builtin_fmaf(t, 16384.0f, static_cast<float>(acc[2][r] * 128 + acc[3][r]));
-        }
-        return fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f);
-    };
-    auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
-#pragma unroll
-        for (int d = 0; d < NDIG; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[d][r] = 0;
-        constexpr int RD = NDIG == 4 ? 2 : 3;
-        v4i wq[RD][NDIG];
-#pragma unroll
-        for (int g = 0; g < RD - 1; ++g)
-#pragma unroll
-            for (int d = 0; d < NDIG; ++d) wq[g][d] = wcl[(g * NDIG + d) * 64];
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            if (ks + RD - 1 < 6) {
-#pragma unroll
-                for (int d = 0; d < NDIG; ++d) wq[(ks + RD - 1) % RD][d] = wcl[((ks + RD - 1) * NDIG + d) * 64];
-            }
-#pragma unroll
-            for (int d = 0; d < NDIG; ++d)
-                acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[ks % RD][d], bfr[ks], acc[d], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, (RD - 1) * NDIG, 0);
-#pragma unroll
-        for (int ks = 0; ks + RD - 1 < 6; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x100, NDIG, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NDIG, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, (RD - 1) * NDIG, 0);
-    };
-    // exchange of one 16-register accumulator between the two roles: 16 bytes per lane per step, lanes contiguous
-    auto send16 = [&](uint8_t *buf, const v16f &v) {
-        v4f *dst = reinterpret_cast<v4f *>(buf + role * 4096) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v4f t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; dst[q * 64] = t; }
-    };
-    auto recv16_add_relu = [&](const uint8_t *buf, v16f &v) {
-        const v4f *src = reinterpret_cast<const v4f *>(buf + (1 - role) * 4096) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const v4f t = src[q * 64];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaxf(v[4 * q + j] + t[j], 0.f);
-        }
-    };
-
-  for (long long cur = wg0; cur < wg1;) {
-    const int4 tile = a.tiles[ti];
-    const int tnb = tile_blocks(tile);
-    if (tnb == 0) { ++ti; continue; }
-    const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
-    const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);
-    const long long row0 = tile.x;
-    const int nrows = static_cast<int>(row0 + tile.y > a.n_rows ? a.n_rows - row0 : tile.y);
-    const int net = min(max(tile.z, 0), a.n_nets - 1);
-    const int flags = tile.w;
-    cur = run_end;
-    if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
-
-    // the pair's first block of the stretch: in flight while (if) the weights are fetched
-    if (first + pair < last) stage_rows_split(a, ldsp, row0 + static_cast<long long>(first + pair) * kRowsPerBlock, lane, role);
-    if (net != loaded_net) {
-        __syncthreads();
-        const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
-        n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
-        {
-            const int n16c = conv_bytes / 16, n16 = n16c + (a.lds_weight_bytes - conv_bytes) / 16;
-            for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
-                const int i = i0 + lane;
-                if (i < n16) {
-                    const uint8_t *src = i < n16c ? blob + a.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
-                }
-            }
-        }
-        w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
-        whg = reinterpret_cast<const v4f *>(blob + a.L.off_head) + lane;
-        bhg = reinterpret_cast<const float *>(blob + a.L.off_bh) + h * 4;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        loaded_net = net;
-    }
-
-    // every wavefront of the workgroup runs the same number of iterations: the exchanges use workgroup barriers
-    for (int it = 0; first + it * 4 < last; ++it) {
-        const int blk = first + it * 4 + pair;
-        bool active = blk < last;
-        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my share of this block's rows has landed (LDS-DMA)
-        __syncthreads();                                              // ... and my partner's
-        if (active && ((flags >> 8) & 0xff) && a.row_select) {        // mixed play: blocks none of whose rows this tile writes
-            const int want = ((flags >> 8) & 0xff) - 1;
-            const bool mine = col + blk * kRowsPerBlock < nrows && a.row_select[brow + col] == want;
-            if (__ballot(mine) == 0) active = false;
-        }
-        v16f h1[2];
-        if (active) {
-            // ---- my positions: role, role + 2, ... (software pipeline as in oc_policy_kernel)
-            int pcur = role, xq = role / PH, yq = role - xq * PH;     // position whose B operands `bfr` holds
-            auto advance2 = [&]() {
-                if (pcur + 2 < P) { pcur += 2; yq += 2; while (yq >= PH) { yq -= PH; ++xq; } }
-            };
-            v4i bfr[6];
-            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
-            v16i acc[NDIG];
-            conv(acc, bfr);
-            advance2();
-            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
-            {
-                const v4f *bq = reinterpret_cast<const v4f *>(b1);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h1[m][r] = role == 0 ? bq[m * 8 + (r >> 2)][r & 3] : 0.f;
-            }
-            v16f x;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = combine(acc, r);
-            for (int k = 0; k < n_pos; ++k) {
-                const int p = role + 2 * k;
-                v4f w1r[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) w1r[q] = w1g[(p * 8 + q) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < n_pos) conv(acc, bfr);
-                __builtin_amdgcn_sched_barrier(0);
-                advance2();
-                read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx) {
-                    h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx) & 3], x[sidx], h1[0], 0, 0, 0);
-                    h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx + 1) & 3], x[sidx], h1[1], 0, 0, 0);
-                    x[sidx] = combine(acc, sidx);
-                }
-            }
-        }
-        // ---- exchange 1 (buffer A): the partner gets my partial of ITS h1 half.  The buffers live in the staging area,
-        // so nothing may be written before BOTH roles have read their last row fragments
-        __syncthreads();
-        if (active) send16(bufA, role == 0 ? h1[1] : h1[0]);
-        __syncthreads();
-        v16f hk, h2[2];
-        if (active) {
-            hk = role == 0 ? h1[0] : h1[1];
-            recv16_add_relu(bufA, hk);                                // relu(h1 half `role`)
-            v4f w2r[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) w2r[q] = w2[(role * 8 + q) * 64];
-            {
-                const v4f *bq = reinterpret_cast<const v4f *>(b2);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h2[m][r] = role == 0 ? bq[m * 8 + (r >> 2)][r & 3] : 0.f;
-            }
-            // ---- fc2: the contribution of input half `role` to both output halves
-#pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx) {
-                h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[sidx >> 1][(2 * sidx) & 3], hk[sidx], h2[0], 0, 0, 0);
-                h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[sidx >> 1][(2 * sidx + 1) & 3], hk[sidx], h2[1], 0, 0, 0);
-            }
-            send16(bufB, role == 0 ? h2[1] : h2[0]);                  // exchange 2 (buffer B)
-        }
-        __syncthreads();
-        v16f out;
-        if (active) {
-            hk = role == 0 ? h2[0] : h2[1];
-            recv16_add_relu(bufB, hk);                                // relu(h2 half `role`)
-            v4f whr[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) whr[q] = whg[(4 * role + q) * 64];
-            const v4f bhv = *reinterpret_cast<const v4f *>(bhg);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[r] = (role == 0 && r < 4) ? bhv[r] : 0.f;
-            // ---- head: the contribution of h2 half `role`
-#pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx)
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[sidx >> 2][sidx & 3], hk[sidx], out, 0, 0, 0);
-            if (role == 1) {                                          // exchange 3: first KiB of buffer A
-                v4f t = {out[0], out[1], out[2], out[3]};
-                reinterpret_cast<v4f *>(bufA)[lane] = t;
-            }
-        }
-        __syncthreads();
-        if (active && role == 0) {
-            const v4f t = reinterpret_cast<const v4f *>(bufA)[lane];
-            out[0] += t[0]; out[1] += t[1]; out[2] += t[2]; out[3] += t[3];
-        }
-        // The area is free again: the pair's next block.  Role 0 stages the piece that covers the exchange-3 words it has
-        // just read (its own LDS read retires before its own DMA is issued), so no further barrier is needed.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (blk + 4 < last) stage_rows_split(a, ldsp, row0 + static_cast<long long>(blk + 4) * kRowsPerBlock, lane, role);
-        if (!active || role != 0) continue;
-
-        // ---- epilogue (role 0), as in oc_policy_kernel
-        const long long row = brow + col;
-        bool valid = (blk * kRowsPerBlock + col) < nrows;
-        const int sel = (flags >> 8) & 0xff;
-        if (sel && a.row_select && valid) valid = a.row_select[row] == sel - 1;
-        if (!(flags & OC_POLICY_TILE_ACT)) {
-            if (valid && a.raw) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * h + r < n_out) a.raw[row * n_out + 4 * h + r] = out[r];
-            }
-            continue;
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) mx = fmaxf(mx, out[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) sum += __expf(out[r] - mx);
-        sum += __shfl_xor(sum, 32);
-        const float lse = mx + __logf(sum);
-        int best = 0;
-        float best_key = -INFINITY, best_lp = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * h + r;
-            if (i < n_out) {
-                const float lp = out[r] - lse;
-                float key = lp;
-                if (a.sample) {
-                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, counter, static_cast<uint32_t>(row), i));
-                    key = lp - __logf(-__logf(u));
-                }
-                if (key > best_key) { best_key = key; best = i; best_lp = lp; }
-                if (valid && a.logp) a.logp[row * n_out + i] = lp;
-            }
-        }
-        {
-            const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
-            const int obest = __shfl_xor(best, 32);
-            if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
-        }
-        if (valid && h == 0) {
-            if (a.actions) a.actions[row] = best;
-            if (a.action_logp) a.action_logp[row] = best_lp;
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Conv / dense kernel: the two wavefronts of a SIMD take different ROLES instead of different rows.  Wavefront w (role C)
-// stages the rows of the pair's block, runs the integer conv of every position and turns the accumulators into the fc1
-// operand -- all of the kernel's LDS fragment reads and nearly all of its VALU work; wavefront w + 4 (role D, same SIMD)
-// runs fc1, fc2, the head and the epilogue -- back-to-back f32 MFMAs with almost no VALU between them.  A wavefront's own
-// VALU work does not hide under its own MFMAs, but one wavefront's VALU and LDS work does hide under the
-// other's MFMAs: this split puts the two kinds of work in different wavefronts by construction, at the LDS footprint of
-// four staging areas -- so it also serves the grids where eight do not fit.  The 16-register operand x of a position
-// travels through one 4 KB LDS slot per pair; two workgroup barriers per position order it (full: C has written x_p; free:
-// D has read it -- D arrives there after issuing its MFMAs, so it never waits for C, which is a position ahead):
-//     C:  ... x_p = combine(conv p) | [free p-1] | write slot | [full p] | conv p+1 ...
-//     D:  [full p] | read slot | prefetch fc1 weights p+1 | 32 MFMAs fc1(p) | [free p] ...
-// Only C touches the staged rows, so the next block's LDS-DMA goes out as soon as C has read its last fragments, under D's
-// last fc1 and dense layers.  LDS: conv digits + 4 x (rows + slot); every dense-layer operand streams from L2 (D
-// double-buffers fc1 per position and fetches fc2 / head under the last position).  The barriers do not wait for
-// vector memory (LDS-DMA and weight prefetches stay in flight across them).
-__device__ __forceinline__ void cf_barrier() {
-    // The scheduling barriers matter as much as the hardware one: MFMAs and VALU work are register-only, so nothing stops
-    // the compiler from sinking "conv p+1; combine" below the barrier they are meant to run ahead of (it does: every phase
-    // then runs back to back, measured), or D's MFMAs below the barrier that releases C.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int NDIG>
-__global__ __launch_bounds__(512) void oc_policy_cf_kernel(const PolicyArgs a) {
-    extern __shared__ uint4 lds_raw[];
-    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave & 3, role = wave >> 2;                      // role 0 = C (conv), 1 = D (dense)
-    const int col = lane & 31, h = lane >> 5;
-    uint8_t *ldsp = lds + a.lds_weight_bytes + static_cast<size_t>(pair) * a.lds_wave_bytes;     // the pair's rows, then its slot
-    v4f *slot = reinterpret_cast<v4f *>(ldsp + a.lds_wave_bytes - 4096) + lane;
-
-    auto tile_blocks = [&](const int4 t) -> int { return policy_tile_blocks(a, t); };
-    long long wg0, wg1, tstart;
-    int ti;
-    if (!policy_find_stretch(a, lane, wg0, wg1, ti, tstart)) return;
-
-    const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
-    const uint32_t counter = a.counter + (a.counter_ptr ? *a.counter_ptr : 0u);
-    const int conv_bytes = static_cast<int>(a.L.off_fc1 - a.L.off_conv);
-    const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
-    const float *sbl = reinterpret_cast<const float *>(lds + (a.L.off_conv_sb - a.L.off_conv)) + h * 16;
-    const uint8_t *rowp = ldsp + col * RB + 16 * h;
-    const int colstep = H * OC_POLICY_C;
-    const v4f *w1g = nullptr, *w2g = nullptr, *whg = nullptr;
-    const float *b1g = nullptr, *b2g = nullptr, *bhg = nullptr;
-    int loaded_net = -1, n_out = 1;
-    bool traced_once = false;
-    auto tstamp = [&](int slot_i) {
-        if (a.trace && lane == 0) a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 32 + slot_i] = wall_clock64();
-    };
-    if (a.trace && lane == 0) a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 32 + 31] = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);
-    tstamp(0);
-
-    auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
-        float t;
-        if (NDIG == 1) t = static_cast<float>(acc[0][r]);
-        else {
-            t = static_cast<float>(acc[0][r] * 128 + acc[1][r]);
-            if (NDIG == 3) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[2][r]));
-            if (NDIG == 4) t = __builtin_fmaf(t, 16384.0f, static_cast<float>(acc[2][r] * 128 + acc[3][r]));
-        }
-        return fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f);
-    };
-    auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
-#pragma unroll
-        for (int d = 0; d < NDIG; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[d][r] = 0;
-        constexpr int RD = NDIG == 4 ? 2 : 3;
-        v4i wq[RD][NDIG];
-#pragma unroll
-        for (int g = 0; g < RD - 1; ++g)
-#pragma unroll
-            for (int d = 0; d < NDIG; ++d) wq[g][d] = wcl[(g * NDIG + d) * 64];
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            if (ks + RD - 1 < 6) {
-#pragma unroll
-                for (int d = 0; d < NDIG; ++d) wq[(ks + RD - 1) % RD][d] = wcl[((ks + RD - 1) * NDIG + d) * 64];
-            }
-#pragma unroll
-            for (int d = 0; d < NDIG; ++d)
-                acc[d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wq[ks % RD][d], bfr[ks], acc[d], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, (RD - 1) * NDIG, 0);
-#pragma unroll
-        for (int ks = 0; ks + RD - 1 < 6; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x100, NDIG, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NDIG, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, (RD - 1) * NDIG, 0);
-    };
-
-  for (long long cur = wg0; cur < wg1;) {
-    const int4 tile = a.tiles[ti];
-    const int tnb = tile_blocks(tile);
-    if (tnb == 0) { ++ti; continue; }
-    const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
-    const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);
-    const long long row0 = tile.x;
-    const int nrows = static_cast<int>(row0 + tile.y > a.n_rows ? a.n_rows - row0 : tile.y);
-    const int net = min(max(tile.z, 0), a.n_nets - 1);
-    const int flags = tile.w;
-    cur = run_end;
-    if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
-
-    // the pair's first block of the stretch (C stages): in flight while (if) the weights are fetched
-    if (role == 0 && first + pair < last) stage_rows(a, ldsp, row0 + static_cast<long long>(first + pair) * kRowsPerBlock, lane);
-    if (net != loaded_net) {
-        __syncthreads();                                              // everybody is done with the previous network's conv digits
-        const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
-        n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
-        for (int i0 = wave * 64; i0 < conv_bytes / 16; i0 += blockDim.x) {
-            const int i = i0 + lane;
-            if (i < conv_bytes / 16)
-                __builtin_amdgcn_global_load_lds((gptr_t)(blob + a.L.off_conv + 16ll * i), (lptr_t)(lds + 16ll * i0), 16, 0, 0);
-        }
-        w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
-        w2g = reinterpret_cast<const v4f *>(blob + a.L.off_fc2) + lane;
-        whg = reinterpret_cast<const v4f *>(blob + a.L.off_head) + lane;
-        b1g = reinterpret_cast<const float *>(blob + a.L.off_b1) + h * 16;
-        b2g = reinterpret_cast<const float *>(blob + a.L.off_b2) + h * 16;
-        bhg = reinterpret_cast<const float *>(blob + a.L.off_bh) + h * 4;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        loaded_net = net;
-    }
-
-    // every wavefront of the workgroup runs the same iterations and the same 2P barriers in each
-    for (int it = 0; first + it * 4 < last; ++it) {
-        const int blk = first + it * 4 + pair;
-        bool active = blk < last;
-        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        if (active && ((flags >> 8) & 0xff) && a.row_select) {        // mixed play: blocks none of whose rows this tile writes
-            const int want = ((flags >> 8) & 0xff) - 1;
-            const bool mine = col + blk * kRowsPerBlock < nrows && a.row_select[brow + col] == want;
-            if (__ballot(mine) == 0) active = false;
-        }
-        if (!active) {
-            // nothing to compute (past the stretch's end, or a mixed-play block none of whose rows this tile writes):
-            // keep the workgroup's barrier count, and keep the pair's staging pipeline going
-            for (int p = 0; p < 2 * P; ++p) cf_barrier();
-            if (role == 0 && blk + 4 < last) stage_rows(a, ldsp, row0 + static_cast<long long>(blk + 4) * kRowsPerBlock, lane);
-            continue;
-        }
-        if (role == 0) {
-            // ================================================ role C: rows -> conv -> x_p ================================================
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's rows have landed (my own LDS-DMA)
-            wave_lds_sync();
-            int pi = 0, xq = 0, yq = 0;
-            auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };
-            v4i bfr[6];
-            v16i acc[NDIG];
-            read_bfrags(rowp, 0, colstep, bfr);
-            conv(acc, bfr);                                           // position 0
-            advance();
-            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
-            for (int p = 0; p < P; ++p) {
-                v16f x;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = combine(acc, r);          // x_p
-                if (p > 0) cf_barrier();                              // free p-1: D has read the slot
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v4f t = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]}; slot[q * 64] = t; }
-                cf_barrier();                                         // full p
-                if (p + 1 < P) {
-                    conv(acc, bfr);                                   // position p+1, under D's fc1 of position p
-                    advance();
-                    read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
-                }
-            }
-            // my last fragment reads are done: the rows are dead, the pair's next block can come in under D's dense layers
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (blk + 4 < last) stage_rows(a, ldsp, row0 + static_cast<long long>(blk + 4) * kRowsPerBlock, lane);
-            cf_barrier();                                             // free P-1
-            if (!traced_once) tstamp(25);
-            traced_once = true;
-            continue;
-        }
-        // ==================================================== role D: fc1, fc2, head, epilogue ====================================================
-        v16f h1[2];
-        {
-            const v4f *bq = reinterpret_cast<const v4f *>(b1g);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h1[m][r] = bq[m * 8 + (r >> 2)][r & 3];
-        }
-        auto read_x = [&](v16f &x) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f t = slot[q * 64];
-                x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
-            }
-        };
-        auto fc1 = [&](const v4f (&w)[8], const v16f &x) {
-#pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx) {
-                h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[sidx >> 1][(2 * sidx) & 3], x[sidx], h1[0], 0, 0, 0);
-                h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[sidx >> 1][(2 * sidx + 1) & 3], x[sidx], h1[1], 0, 0, 0);
-            }
-        };
-        {
-            // two operand sets, used alternately: the loads of position p+1 are issued right behind the barrier and stay in
-            // flight under the 32 MFMAs of position p (no register copies, nothing that needs them before the next step)
-            v4f wa[8], wb[8];
-            auto load_w1 = [&](v4f (&w)[8], int p) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = w1g[(p * 8 + q) * 64];
-            };
-            auto step = [&](const v4f (&cur)[8], v4f (&nxt)[8], int p) {     // positions 0 .. P-2
-                cf_barrier();                                         // full p
-                load_w1(nxt, p + 1);
-                __builtin_amdgcn_sched_barrier(0);                    // (left alone, the scheduler sinks these loads to the end of the MFMAs)
-                v16f x;
-                read_x(x);
-                fc1(cur, x);
-                // "land" the next operands here, behind the MFMAs that covered their flight: the compiler's vmcnt bookkeeping
-                // then knows them present and does not put a full vmcnt(0) in front of the next step's MFMAs (it did)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(nxt[q]));
-                cf_barrier();                                         // free p (my MFMAs are issued: C, a position ahead, is waiting here)
-            };
-            load_w1(wa, 0);                                           // in flight while C finishes x_0
-            int p = 0;
-            for (; p + 2 < P; p += 2) {
-                step(wa, wb, p);
-                step(wb, wa, p + 1);
-            }
-            if (p + 1 < P) {                                          // P even: one more full step, the last position uses wb
-                step(wa, wb, p);
-                cf_barrier();                                         // full P-1
-                v16f x;
-                read_x(x);
-                fc1(wb, x);
-            } else {                                                  // P odd: the last position uses wa
-                cf_barrier();                                         // full P-1
-                v16f x;
-                read_x(x);
-                fc1(wa, x);
-            }
-        }
-        // dense-layer operands from L2: requested now, under the last position's MFMAs
-        v4f w2r[2][8], whr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { w2r[0][q] = w2g[q * 64]; w2r[1][q] = w2g[(8 + q) * 64]; whr[q] = whg[q * 64]; }
-        cf_barrier();                                                 // free P-1
-        if (!traced_once) tstamp(25);
-        v16f h2[2], out;
-        {
-            const v4f *bq = reinterpret_cast<const v4f *>(b2g);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h2[m][r] = bq[m * 8 + (r >> 2)][r & 3];
-            const v4f bhv = *reinterpret_cast<const v4f *>(bhg);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[r] = r < 4 ? bhv[r] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1[0][r] = fmaxf(h1[0][r], 0.f);
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx) & 3], h1[0][sidx], h2[0], 0, 0, 0);
-            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx + 1) & 3], h1[0][sidx], h2[1], 0, 0, 0);
-            h1[1][sidx] = fmaxf(h1[1][sidx], 0.f);
-        }
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx) & 3], h1[1][sidx], h2[0], 0, 0, 0);
-            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx + 1) & 3], h1[1][sidx], h2[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[0][r] = fmaxf(h2[0][r], 0.f);
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[sidx >> 2][sidx & 3], h2[0][sidx], out, 0, 0, 0);
-            h2[1][sidx] = fmaxf(h2[1][sidx], 0.f);
-        }
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx)
-            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[4 + (sidx >> 2)][sidx & 3], h2[1][sidx], out, 0, 0, 0);
-
-        if (!traced_once) tstamp(26);                                 // dense layers issued
-        traced_once = true;
-        // ---- epilogue, as in oc_policy_kernel
-        const long long row = brow + col;
-        bool valid = (blk * kRowsPerBlock + col) < nrows;
-        const int sel = (flags >> 8) & 0xff;
-        if (sel && a.row_select && valid) valid = a.row_select[row] == sel - 1;
-        if (!(flags & OC_POLICY_TILE_ACT)) {
-            if (valid && a.raw) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * h + r < n_out) a.raw[row * n_out + 4 * h + r] = out[r];
-            }
-            continue;
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) mx = fmaxf(mx, out[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) sum += __expf(out[r] - mx);
-        sum += __shfl_xor(sum, 32);
-        const float lse = mx + __logf(sum);
-        int best = 0;
-        float best_key = -INFINITY, best_lp = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * h + r;
-            if (i < n_out) {
-                const float lp = out[r] - lse;
-                float key = lp;
-                if (a.sample) {
-                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, counter, static_cast<uint32_t>(row), i));
-                    key = lp - __logf(-__logf(u));
-                }
-                if (key > best_key) { best_key = key; best = i; best_lp = lp; }
-                if (valid && a.logp) a.logp[row * n_out + i] = lp;
-            }
-        }
-        {
-            const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
-            const int obest = __shfl_xor(best, 32);
-            if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
-        }
-        if (valid && h == 0) {
-            if (a.actions) a.actions[row] = best;
-            if (a.action_logp) a.action_logp[row] = best_lp;
-        }
-    }
-  }
-}
-
 __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
     const long long words = L.total / 4;
     for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < words;
@@ -1361,59 +687,36 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
         if (w_conv + w_tail_all + 4 * obs1 <= kLds) fc1_lds = true;
         else if (w_conv + w_tail_small + 4 * obs1 > kLds) conv_lds = false;
     }
-    // Pair plan (oc_policy_pair_kernel): when eight staging areas do not fit, two wavefronts per SIMD share four of them
-    // and split each block's conv positions; LDS = conv digits + [b1 | fc2 | b2] + 4 pair areas (fc1 and head from L2)
-    const long long w_pair_tail = a.L.off_head - a.L.off_b1;
-    const long long pair_area = std::max<long long>(a.lds_wave_bytes, (kPairExchangeBytes + 15) / 16 * 16);
-    // Measured (profiles/r02_policy_pair_split.log): correct, but SLOWER than one wavefront per SIMD -- asymmetric_advantages
-    // 205 vs 176 us for 122 880 evaluations, config 4's per-GPU share 114 vs 93 us per step: five workgroup barriers per
-    // block and both roles reaching the exchanges together cost more than the interleaving of the position loops gains.
-    // Kept selectable (OC_POLICY_PLAN=pair) and tested; not the default.
-    bool pair = false;
-    // Conv / dense plan (oc_policy_cf_kernel): roles instead of rows; LDS = conv digits + 4 x (rows + 4 KB operand slot)
-    const long long cf_area = a.lds_wave_bytes + 4096;
-    const bool cf_fits = w_conv + 4 * cf_area <= kLds;
-    bool cf = false;
-    const char *const env_plan = getenv("OC_POLICY_PLAN");           // "waves,fc1_lds,conv_lds" | "pair" | "cf" | "rows" (read per call: tests switch it)
+    // Two cooperative plans for the grids where eight staging areas do not fit were built and measured in round 2 -- two
+    // wavefronts of a SIMD sharing one staged block and splitting its conv positions, and a conv-wavefront / dense-wavefront
+    // role split -- both parity-green and both 20-30 % SLOWER than one wavefront per SIMD (commits 'pair plan' / 'conv/dense
+    // role split'; profiles/r02_policy_pair_split.log, r02_policy_conv_dense_split.log).  tools/probes/coexec.hip shows why:
+    // on one gfx950 SIMD a partner wavefront's VALU work does not overlap back-to-back MFMAs of any type (both together cost
+    // the sum, not the maximum), so a second wavefront per SIMD can only fill MFMA-free gaps, not hide work.
+    const char *const env_plan = getenv("OC_POLICY_PLAN");           // diagnostics: "waves,fc1_lds,conv_lds" (read per call)
     if (env_plan && env_plan[0]) {
         int w = 0, f = 0, c = 0;
-        if (!strcmp(env_plan, "pair")) pair = a.L.P >= 2 && w_conv + w_pair_tail + 4 * pair_area <= kLds;
-        else if (!strcmp(env_plan, "cf")) cf = cf_fits;
-        else if (!strcmp(env_plan, "rows")) { pair = false; cf = false; }
-        else if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; pair = false; cf = false; }
+        if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
-    if (cf) {
-        waves = 8; fc1_lds = false; conv_lds = true;
-        a.lds_wave_bytes = static_cast<int>(cf_area);
-        a.lds_weight_bytes = static_cast<int>(w_conv);
-    } else if (pair) {
-        waves = 8; fc1_lds = false; conv_lds = true;
-        a.lds_wave_bytes = static_cast<int>(pair_area);
-        a.lds_weight_bytes = static_cast<int>(w_conv + w_pair_tail);
-    } else {
-        a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
-        while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
-    }
-    const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>((pair || cf) ? 4 : waves) * a.lds_wave_bytes;
+    a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
+    while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
+    const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
     if (lds > static_cast<size_t>(kLds)) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
     typedef void (*kernel_t)(const PolicyArgs);
-    static const kernel_t pair_kernels[4] = {oc_policy_pair_kernel<1>, oc_policy_pair_kernel<2>, oc_policy_pair_kernel<3>, oc_policy_pair_kernel<4>};
-    static const kernel_t cf_kernels[4] = {oc_policy_cf_kernel<1>, oc_policy_cf_kernel<2>, oc_policy_cf_kernel<3>, oc_policy_cf_kernel<4>};
     static const kernel_t kernels[4][2][2] = {
         {{oc_policy_kernel<1, false, false>, oc_policy_kernel<1, false, true>}, {oc_policy_kernel<1, true, false>, oc_policy_kernel<1, true, true>}},
         {{oc_policy_kernel<2, false, false>, oc_policy_kernel<2, false, true>}, {oc_policy_kernel<2, true, false>, oc_policy_kernel<2, true, true>}},
         {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
-    const kernel_t kernel = cf ? cf_kernels[shape->digits - 1] : pair ? pair_kernels[shape->digits - 1] : kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(d_packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2] = {}, lds_granted_pair[64][4] = {}, lds_granted_cf[64][4] = {};   // largest opt-in already set per device and kernel instance
-    size_t &granted = cf ? lds_granted_cf[dev][shape->digits - 1] : pair ? lds_granted_pair[dev][shape->digits - 1]
-                                                                          : lds_granted[dev][shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    static size_t lds_granted[64][4][2][2] = {};                      // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Policy kernel on the grids whose staging areas limit LDS to four (asymmetric_advantages, counter_circuit, the 5x5
+"""[Historical: the plans this script compares (OC_POLICY_PLAN=pair / cf) were removed from the product after they measured slower;
+check out the commits named in DESIGN.md 9a to re-run it.  Logs: profiles/r02_policy_pair_split.log, r02_policy_conv_dense_split.log]
+
+Policy kernel on the grids whose staging areas limit LDS to four (asymmetric_advantages, counter_circuit, the 5x5
 layouts): the pair plan (two wavefronts per SIMD sharing one staged block, oc_policy_pair_kernel) against the
 one-wavefront-per-SIMD plan.  OC_POLICY_PLAN is read once per process: run once with OC_POLICY_PLAN=nopair, once without.
 Prints per layout the policy launch alone (actors + critics, both sides) and the whole step of config 4's per-GPU share."""
