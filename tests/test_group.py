@@ -26,9 +26,11 @@ def test_group_module_compiles_and_plan_gives_one_group_per_wavefront(layout_par
         assert kpw % 4 == 0 and 4 <= kpw <= 64 and (kpw * S * 5) % 4 == 0
         assert blocks == -(-8192 // kpw), "config 3 fits one group per wavefront: nobody gets two"
         tiles.append(kpw * S)
-    assert sum(b for _, b in plan) <= 8 * 256
-    even = sum(8192 * p["width"] * p["height"] for p in ps) / (8 * 256)          # tiles per wavefront of a perfect split
-    assert max(tiles) <= 1.15 * even, f"unbalanced wavefronts: {tiles} tiles per group, {even:.0f} if split evenly"
+    assert sum(b for _, b in plan) <= 12 * 256
+    even = sum(8192 * p["width"] * p["height"] for p in ps) / (12 * 256)         # tiles per wavefront of a perfect split
+    # groups come in steps of 4 kitchens, so the best reachable budget sits within one step (4 x the largest grid) of an even split
+    step = 4 * max(p["width"] * p["height"] for p in ps)
+    assert max(tiles) <= even + step, f"unbalanced wavefronts: {tiles} tiles per group, {even:.0f} if split evenly"
 
 
 def test_group_plan_large_batches_share_wavefronts_by_tiles(layout_params):
@@ -37,7 +39,7 @@ def test_group_plan_large_batches_share_wavefronts_by_tiles(layout_params):
     _, plan = native.jit_compile_check_group(ps, [65536] * 5)
     blocks = np.array([b for _, b in plan], dtype=np.float64)
     tiles = np.array([65536 * p["width"] * p["height"] for p in ps], dtype=np.float64)
-    assert blocks.sum() <= 8 * 256 and blocks.sum() >= 8 * 256 - 5
+    assert blocks.sum() <= 12 * 256 and blocks.sum() >= 12 * 256 - 5
     assert np.abs(blocks / blocks.sum() - tiles / tiles.sum()).max() < 0.01
 
 

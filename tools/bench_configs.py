@@ -150,10 +150,13 @@ if __name__ == "__main__":
     if "--group" in sys.argv:
         print(json.dumps(config3()), flush=True)
         print(json.dumps(config3_group()), flush=True)
-        print(json.dumps(config3_group(wpc=9)), flush=True)
-        print(json.dumps(config3_group(kpw=[32, 16, 24, 24, 16])), flush=True)
         print(json.dumps(config3_group(passes=2)), flush=True)
+        print(json.dumps(config3_group(wpc=12)), flush=True)
+        print(json.dumps(config3_group(wpc=12, passes=2)), flush=True)
+        print(json.dumps(config3_group(wpc=10, passes=2)), flush=True)
+        print(json.dumps(config3_group(kpw=[16, 8, 16, 16, 8], passes=2, wpc=12)), flush=True)
         print(json.dumps(config3_group(n=65536, T=100)), flush=True)
+        print(json.dumps(config3_group(n=65536, T=100, passes=2, wpc=12)), flush=True)
         sys.exit(0)
     if "--policies" in sys.argv:
         print(json.dumps(config3_policies(critics=False)), flush=True)
