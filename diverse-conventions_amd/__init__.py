@@ -5,7 +5,7 @@
 from .layouts import ALIASES, CLASSIC_LAYOUTS, get_base_layout_params, layout_names
 from .vector_api import PlayerException, RandomVectorAgent, VectorAgent, VectorMultiAgentEnv, VectorObservation
 from .engine import OvercookedEngine
-from .group import EngineGroup
+from .group import EngineGroup, GroupPairedRollout
 from .overcooked_env import OvercookedMadrona
 from .env_utils import generate_env
 from .trajectory import TrajectoryBuffer
@@ -19,6 +19,6 @@ from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments,
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
-    "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "EngineGroup", "OvercookedMadrona",
+    "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "EngineGroup", "GroupPairedRollout", "OvercookedMadrona",
     "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "StackedActors", "StackedCritics", "PairedRollout", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
 ]

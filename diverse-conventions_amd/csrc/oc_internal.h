@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 int oc_internal_fail(int code, const char *fmt, ...);      // overcooked_engine.hip: sets oc_last_error()
+struct oc_group;
+struct oc_engine;
+oc_engine *oc_internal_group_engine(oc_group *g, int i);    // overcooked_engine.hip: engine i of a group (NULL if out of range)
 
 // Every launching entry point runs with the GPU that owns its buffers current, whatever the caller's (or torch's)
 // current device is, and puts the caller's device back on return: kernels are enqueued on streams of that GPU, and

@@ -649,7 +649,16 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
                       float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                       const int32_t *d_row_select, void *stream) {
+    return oc_policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode,
+                                 seed, counter, d_counter, d_row_select, 0, stream);
+}
+
+int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                          const int32_t *d_row_select, int32_t cu_budget, void *stream) {
     if (int rc = check_shape(shape, "oc_policy_forward")) return rc;
+    if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
     if (!d_packed || !d_obs || !d_tiles || n_nets < 1 || n_rows < 1 || n_tiles < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
     if ((reinterpret_cast<uintptr_t>(d_packed) & 15) || (reinterpret_cast<uintptr_t>(d_obs) & 3) || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
@@ -731,7 +740,8 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
             return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot query the CU count");
         cus_of[dev] = v;
     }
-    const int n_cus = cus_of[dev];
+    // the launch is sized for the CUs its stream may use: the whole device, or a CU-masked stream's share (oc_cu_partition_create)
+    const int n_cus = cu_budget > 0 ? std::min<int>(cu_budget, cus_of[dev]) : cus_of[dev];
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
@@ -770,6 +780,139 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
         if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n, stream)) return rc;
     }
     return OC_OK;
+}
+
+int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus) {
+    if (!shares || !out_streams || n < 1 || n > 64) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_cu_partition_create: 1..64 streams");
+    const OcDeviceScope on_device(device_id);
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: cannot make device %d current", device_id);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < n || cus > 1024)
+        return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: %d CUs cannot be shared out over %d streams", cus, n);
+    double total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!(shares[i] > 0.f)) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_cu_partition_create: shares must be positive");
+        total += shares[i];
+    }
+    // CUs per stream: proportional, at least one, largest remainders first
+    std::vector<int> want(n);
+    int used = 0;
+    for (int i = 0; i < n; ++i) { want[i] = std::max(1, static_cast<int>(shares[i] / total * cus)); used += want[i]; }
+    while (used < cus) {
+        int best = 0;
+        for (int i = 1; i < n; ++i)
+            if (shares[i] / want[i] > shares[best] / want[best]) best = i;
+        ++want[best]; ++used;
+    }
+    while (used > cus) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)
+            if (want[i] > 1 && (best < 0 || shares[i] / want[i] < shares[best] / want[best])) best = i;
+        --want[best]; --used;
+    }
+    // every stream's CUs spread over the whole index range (weighted round robin), so each share touches every XCD / memory channel
+    std::vector<std::vector<uint32_t>> mask(n, std::vector<uint32_t>((cus + 31) / 32, 0u));
+    std::vector<int> given(n, 0);
+    for (int c = 0; c < cus; ++c) {
+        int best = -1;
+        double lag = -1e30;
+        for (int i = 0; i < n; ++i) {
+            if (given[i] >= want[i]) continue;
+            const double l = static_cast<double>(c + 1) * want[i] / cus - given[i];     // how far behind its even pace stream i is
+            if (l > lag) { lag = l; best = i; }
+        }
+        mask[best][c / 32] |= 1u << (c % 32);
+        ++given[best];
+    }
+    for (int i = 0; i < n; ++i) out_streams[i] = nullptr;
+    for (int i = 0; i < n; ++i) {
+        hipStream_t st = nullptr;
+        const hipError_t e = hipExtStreamCreateWithCUMask(&st, static_cast<uint32_t>(mask[i].size()), mask[i].data());
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipStreamDestroy(static_cast<hipStream_t>(out_streams[j]));
+            return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        }
+        out_streams[i] = st;
+        if (out_cus) out_cus[i] = want[i];
+    }
+    return OC_OK;
+}
+
+int oc_cu_partition_destroy(void *const *streams, int32_t n) {
+    if (!streams) return OC_OK;
+    for (int i = 0; i < n; ++i)
+        if (streams[i]) {
+            (void)hipStreamSynchronize(static_cast<hipStream_t>(streams[i]));
+            (void)hipStreamDestroy(static_cast<hipStream_t>(streams[i]));
+        }
+    return OC_OK;
+}
+
+int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets, int64_t T,
+                            int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
+    const int n = oc_group_size(g);
+    if (n < 1 || !slots || T < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL group / slots or negative T");
+    std::vector<oc_engine *> eng(n);
+    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n);
+    for (int i = 0; i < n; ++i) {
+        eng[i] = oc_internal_group_engine(g, i);
+        int64_t shp[5];
+        if (int rc = oc_obs_shape(eng[i], shp)) return rc;
+        const oc_group_policy_slot &s = slots[i];
+        if (!s.shape || !s.d_packed || !s.d_tiles || !s.d_obs || !s.d_actions || !s.d_reward || !s.d_done)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL pointer in slot %d", i);
+        if (shp[2] != s.shape->width || shp[3] != s.shape->height)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: the networks' grid of slot %d does not match its engine's", i);
+        kitchens[i] = shp[1]; rows[i] = 2 * shp[1]; slot_bytes[i] = rows[i] * shp[2] * shp[3] * shp[4];
+    }
+    const OcDeviceScope on_device(oc_device_id(eng[0]));
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: cannot make device %d current", oc_device_id(eng[0]));
+    hipStream_t main_stream = static_cast<hipStream_t>(stream);
+    // fork / join events: policies of step t wait for the env step of t-1; the env step waits for every policy launch
+    std::vector<hipEvent_t> pol_done(n, nullptr);
+    hipEvent_t env_done = nullptr;
+    auto cleanup = [&]() {
+        for (hipEvent_t e : pol_done) if (e) (void)hipEventDestroy(e);
+        if (env_done) (void)hipEventDestroy(env_done);
+    };
+    bool any_side = false;
+    for (int i = 0; i < n; ++i) any_side = any_side || (policy_streams && policy_streams[i] && policy_streams[i] != stream);
+    if (any_side) {
+        hipError_t e = hipEventCreateWithFlags(&env_done, hipEventDisableTiming);
+        for (int i = 0; i < n && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pol_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) { cleanup(); return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event creation failed: %s", hipGetErrorString(e)); }
+    }
+    std::vector<const void *> act(n);
+    std::vector<int8_t *> obs_next(n);
+    std::vector<int32_t *> rew(n), done(n);
+    int rc = OC_OK;
+    for (int64_t t = 0; t < T && rc == OC_OK; ++t) {
+        const int64_t k = in_place ? 0 : t;
+        if (any_side && hipEventRecord(env_done, main_stream) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event record failed");
+        for (int i = 0; i < n && rc == OC_OK; ++i) {
+            const oc_group_policy_slot &s = slots[i];
+            hipStream_t ps = (policy_streams && policy_streams[i]) ? static_cast<hipStream_t>(policy_streams[i]) : main_stream;
+            const bool side = ps != main_stream;
+            if (side && hipStreamWaitEvent(ps, env_done, 0) != hipSuccess) { rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: stream wait failed"); break; }
+            int8_t *obs_t = s.d_obs + k * slot_bytes[i];
+            int32_t *act_t = s.d_actions + k * rows[i];
+            rc = oc_policy_forward_cus(s.shape, s.d_packed, s.n_nets, obs_t, rows[i], s.d_tiles, s.n_tiles, s.d_values ? s.d_values + k * rows[i] : nullptr,
+                                       act_t, s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr, nullptr, sample_mode, seed + static_cast<uint32_t>(i) * 0x9E3779B9u,
+                                       counter0 + static_cast<uint32_t>(t), nullptr, nullptr, side && cu_budgets ? cu_budgets[i] : 0, ps);
+            if (rc == OC_OK && side && hipEventRecord(pol_done[i], ps) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event record failed");
+            act[i] = act_t;
+            obs_next[i] = in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i];
+            rew[i] = s.d_reward + k * rows[i];
+            done[i] = s.d_done + k * kitchens[i];
+        }
+        for (int i = 0; i < n && rc == OC_OK; ++i) {
+            hipStream_t ps = (policy_streams && policy_streams[i]) ? static_cast<hipStream_t>(policy_streams[i]) : main_stream;
+            if (ps != main_stream && hipStreamWaitEvent(main_stream, pol_done[i], 0) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: stream wait failed");
+        }
+        if (rc == OC_OK) rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream);
+    }
+    cleanup();
+    return rc;
 }
 
 /* Diagnostics, deliberately not in the public header: per-wavefront phase stamps of the following launches

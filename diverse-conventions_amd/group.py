@@ -108,3 +108,113 @@ class EngineGroup:
     def set_tuning(self, kitchens_per_wave: Optional[Sequence[int]] = None, passes_per_flush: int = 0, waves_per_cu: int = 0):
         kpw = None if kitchens_per_wave is None else (ctypes.c_int32 * len(self.engines))(*[int(k) for k in kitchens_per_wave])
         native.check(self._L.oc_group_set_tuning(self._handle, kpw, passes_per_flush, waves_per_cu))
+
+
+class GroupPairedRollout:
+    """Convention-paired rollout over the engines of an `EngineGroup` with the policies in the loop: per joint step every
+    engine's fused policy launch (all conventions' actors, optionally critics, both sides, every pairing segment -- what
+    `FusedPairedRollout` does for one engine) and then ONE env launch for all engines.  The policy launches of the five layouts
+    are each too small to fill an MI355X (8190 kitchens are two 32-row blocks per CU), so they run SIDE BY SIDE on CU-masked
+    streams whose shares follow each layout's policy work (`oc_cu_partition_create`), forked off and joined around the env
+    step by events; all steps are enqueued from C (`oc_group_policy_rollout`).  The reference does this as five simulators and
+    5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26, train/XD/xd_player.py:190-207).
+
+    nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
+    critic_nets[i][side][g] as in FusedPairedRollout (or None)."""
+
+    def __init__(self, group: EngineGroup, nets, threads, n_conventions: int, critic_nets=None, deterministic: bool = False, seed: int = 0,
+                 partition: bool = True):
+        from .fused_policy import TILE_ACT, PolicyPlan, _shape
+        from .policy import segment_policy_indices
+        from .sharding import pairing_segments
+        self.group, self.nets, self.deterministic, self.seed = group, list(nets), deterministic, int(seed)
+        n_eng = len(group)
+        self.threads = [threads] * n_eng if isinstance(threads, int) else list(threads)
+        self.segments, rows_all, work = [], [], []
+        for i, (e, nt, th) in enumerate(zip(group.engines, self.nets, self.threads)):
+            segs = pairing_segments(th, n_conventions)
+            g, n = len(segs), e.num_kitchens
+            if n != g * th:
+                raise ValueError(f"engine {i} must hold threads*(2k+1) = {g * th} kitchens")
+            actors = [segment_policy_indices(segs, "ego"), segment_policy_indices(segs, "partner")]
+            rows = []
+            for side in range(2):
+                for s in range(g):
+                    rows.append((side * n + s * th, th, actors[side][s], TILE_ACT))
+                    if critic_nets is not None and critic_nets[i] is not None:
+                        rows.append((side * n + s * th, th, critic_nets[i][side][s], 0))
+            self.segments.append(segs)
+            rows_all.append(rows)
+            positions = (e.width - 2) * (e.height - 2)                     # MFMA + VALU cycles per 32-row block (DESIGN.md 9a)
+            work.append(len(rows) * th / 32.0 * (positions * 4100.0 + 8500.0))
+        self.has_critics = [critic_nets is not None and critic_nets[i] is not None for i in range(n_eng)]
+        L = native.lib()
+        self._L = L
+        self._streams = (_vp * n_eng)()
+        self._cus = (ctypes.c_int32 * n_eng)()
+        self._partitioned = bool(partition) and n_eng > 1
+        if self._partitioned:
+            shares = (ctypes.c_float * n_eng)(*[w / sum(work) for w in work])
+            native.check(L.oc_cu_partition_create(group.device.index or 0, shares, n_eng, self._streams, self._cus))
+        cus_total = torch.cuda.get_device_properties(group.device).multi_processor_count
+        self.plans = [PolicyPlan(nt, 2 * e.num_kitchens, rows, rows_per_tile=-(int(self._cus[i]) if self._partitioned else cus_total))
+                      for i, (e, nt, rows) in enumerate(zip(group.engines, self.nets, rows_all))]
+        dev = group.device
+        self.actions = [torch.zeros((2, e.num_kitchens), dtype=torch.int32, device=dev) for e in group.engines]
+        self.logp = [torch.zeros((2, e.num_kitchens), dtype=torch.float32, device=dev) for e in group.engines]
+        self.values = [torch.zeros((2, e.num_kitchens), dtype=torch.float32, device=dev) if c else None
+                       for e, c in zip(group.engines, self.has_critics)]
+        self._shapes = [_shape(nt.W, nt.H, 6, nt.digits) for nt in self.nets]
+        self.steps_done = 0
+
+    @property
+    def cu_shares(self):
+        """CUs given to each engine's policy stream (whole device each when not partitioned)."""
+        return [int(c) for c in self._cus] if self._partitioned else None
+
+    def _run(self, T, in_place, obs, actions, logp, values, reward, done):
+        p = lambda t: _vp(t.data_ptr()) if t is not None else None
+        slots = (native.OcGroupPolicySlot * len(self.group))()
+        for i, (nt, plan) in enumerate(zip(self.nets, self.plans)):
+            s = slots[i]
+            s.shape = ctypes.pointer(self._shapes[i])
+            s.d_packed, s.n_nets, s.d_tiles, s.n_tiles = p(nt.image), nt.n_nets, p(plan.tiles), plan.n_tiles
+            s.d_obs, s.d_actions, s.d_action_logp, s.d_values = p(obs[i]), p(actions[i]), p(logp[i]), p(values[i])
+            s.d_reward, s.d_done = p(reward[i]), p(done[i])
+        native.check(self._L.oc_group_policy_rollout(
+            self.group._handle, slots, self._streams if self._partitioned else None, self._cus if self._partitioned else None, int(T),
+            1 if in_place else 0, 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
+        self.steps_done += int(T)
+
+    def step(self, steps: int = 1):
+        """`steps` joint steps, outputs overwritten in place in every engine's own buffers."""
+        es = self.group.engines
+        self._run(steps, True, [e.obs for e in es], self.actions, self.logp, self.values, [e.reward for e in es], [e.done for e in es])
+        return [e.obs for e in es], [e.reward for e in es], [e.done for e in es]
+
+    def collect(self, trajs, logps=None, values=None):
+        """Fill one TrajectoryBuffer per engine (same length T): step t reads slot t of each, writes actions into it and the env
+        launch writes every engine's slot t+1.  logps / values: optional lists of float32 [T, 2, N_i] tensors."""
+        T = trajs[0].T
+        if any(t.T != T for t in trajs):
+            raise ValueError("the trajectories of a group rollout must share one length")
+        for t in trajs:
+            t.start()
+        none = [None] * len(trajs)
+        self._run(T, False, [t.obs for t in trajs], [t.actions for t in trajs], logps or none, values or none,
+                  [t.reward for t in trajs], [t.done for t in trajs])
+        for t in trajs:
+            t.t = T
+        return trajs
+
+    def close(self):
+        if self._partitioned and self._streams is not None:
+            torch.cuda.synchronize(self.group.device)
+            self._L.oc_cu_partition_destroy(self._streams, len(self.group))
+            self._streams = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

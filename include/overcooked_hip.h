@@ -76,6 +76,7 @@ typedef struct {
 } oc_layout_params;
 
 typedef struct oc_engine oc_engine;
+typedef struct oc_group oc_group;      /* several engines stepped by one launch, see oc_group_create */
 
 /* replaces Manager::Manager(Config) (mgr.cpp:179-206) / SimplecookedSimulator.__init__.
  * Allocates the state block for n_kitchens kitchens on device_id and puts every kitchen in the
@@ -155,7 +156,6 @@ int oc_encode_trajectory(oc_engine *e, const void *d_states, int64_t n, int64_t 
  * The pointer tables are HOST arrays of oc_group_size() device pointers, in the order of oc_group_create; buffers, dtypes
  * and results per engine are exactly those of oc_step / oc_observe.  Without a usable hiprtc the calls fall back to one
  * launch per engine, same results (oc_group_build_info says which). */
-typedef struct oc_group oc_group;
 int oc_group_create(oc_engine *const *engines, int32_t n_engines, oc_group **out);
 int oc_group_destroy(oc_group *g);                    /* the engines stay alive and belong to the caller */
 int32_t oc_group_size(const oc_group *g);
@@ -288,6 +288,42 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                       float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                       const int32_t *d_row_select, void *stream);
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
+/* oc_policy_forward sized for a SHARE of the GPU: cu_budget = number of CUs the stream may use (a CU-masked stream from
+ * oc_cu_partition_create; 0 = the whole device).  One workgroup per CU of the budget; plan the tile table for it
+ * (oc_policy_plan_tiles(..., -cu_budget, ...)). */
+int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                          const int32_t *d_row_select, int32_t cu_budget, void *stream);
+/* n HIP streams restricted to disjoint sets of the device's CUs, stream i getting about shares[i] / sum(shares) of them (at
+ * least one; every set spread over the whole CU index range).  For launches that cannot fill the chip on their own -- one
+ * layout's policies at a few thousand kitchens are two 32-row blocks per CU -- running them side by side on their own CUs
+ * is what one bigger launch would do: two asymmetric_advantages policy launches of 8184 kitchens take 49.6 us together on two
+ * half-device streams against 91 us one after the other (or on two unmasked streams).  out_streams: n hipStream_t (as void*),
+ * out_cus (optional): CUs given to each.  Destroy with oc_cu_partition_destroy. */
+int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus);
+int oc_cu_partition_destroy(void *const *streams, int32_t n);
+/* T joint rollout steps of a group with the policies in the loop, enqueued from C: per step every engine's policy launch
+ * (on policy_streams[i], sized for cu_budgets[i] CUs; NULL tables / entries = `stream`, whole device) followed by ONE env launch
+ * for all engines (oc_group_step on `stream`); events fork the policy streams off the env step and join them before the next
+ * one.  The reference's five-layout training / evaluation loop (BASELINE configs 3 and 5) as 5 + 1 launches per joint step,
+ * the five running side by side.  slots[i] describes engine i exactly as oc_policy_rollout's arguments do (same buffers, same
+ * in_place meaning; draw counter of step t = counter0 + t, seed offset per engine). */
+typedef struct {
+    const oc_policy_shape *shape;
+    const void *d_packed;
+    int32_t n_nets;
+    const int32_t *d_tiles;
+    int32_t n_tiles;
+    int8_t *d_obs;
+    int32_t *d_actions;
+    float *d_action_logp;      /* may be NULL */
+    float *d_values;           /* may be NULL */
+    int32_t *d_reward;
+    int32_t *d_done;
+} oc_group_policy_slot;
+int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets, int64_t T,
+                            int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
 /* T rollout steps with the policies in the loop, enqueued from C (no host work between launches): per step one
  * oc_policy_forward over the 2N rows of the engine's observation (tiles address rows player * N + kitchen; critic
  * tiles write d_values) and one oc_step.  What XDPlayer.next_step does per step through 2(2k+1) get_actions calls

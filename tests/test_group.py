@@ -252,3 +252,70 @@ def test_the_group_binding_shown_in_integration_md_runs(layout_params):
         grp.step()
         for a, b in zip(solo, sims):
             assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", [True, False])
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deterministic, layout_params):
+    """Policies in the loop over three layouts: per joint step three policy launches side by side on CU-masked streams
+    (or all on the launch stream) and ONE env launch.  Every engine's collected trajectory -- actions, log-probs, values,
+    observations, rewards, dones -- must be exactly what its own FusedPairedRollout collects with the same seed, and the env
+    oracle driven by the recorded actions must reproduce the observations."""
+    from diverse_conventions_amd import (EngineGroup, FusedPairedRollout, GroupPairedRollout, OvercookedEngine, PackedNetworks,
+                                         TrajectoryBuffer)
+    names, threads, k, T = ["simple", "random0", "unident_s"], [48, 33, 20], 2, 14
+    G = 2 * k + 1
+    rng = np.random.default_rng(5)
+    r = lambda *s: (rng.standard_normal(s) * 0.1).astype(np.float32)
+    nets, critic_of = [], []
+    for nm in names:
+        p = layout_params[nm]
+        W, H = p["width"], p["height"]
+        P = (W - 2) * (H - 2)
+        trunk = lambda: {"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+                         "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64)}
+        actors = [dict(trunk(), **{"act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)}) for _ in range(k + 1)]
+        critics = [dict(trunk(), **{"v_out.weight": r(1, 64), "v_out.bias": r(1)}) for _ in range(2)]
+        nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=critics))
+        critic_of.append([[k + 1 + (g % 2) for g in range(G)], [k + 1 + ((g + 1) % 2) for g in range(G)]])
+    make = lambda: [OvercookedEngine(layout_params[nm], th * G, 0) for nm, th in zip(names, threads)]
+    seed = 77
+    # reference: every engine on its own, one after the other
+    want = []
+    for i, e in enumerate(make()):
+        ro = FusedPairedRollout(e, nets[i], threads[i], k, critic_nets=critic_of[i], deterministic=deterministic,
+                                seed=(seed + i * 0x9E3779B9) & 0xFFFFFFFF)
+        tr = TrajectoryBuffer(e, T)
+        lp, va = torch.zeros((T, 2, e.num_kitchens), device="cuda"), torch.zeros((T, 2, e.num_kitchens), device="cuda")
+        ro.collect(tr, logp=lp, values=va)
+        want.append((tr, lp, va))
+    engines = make()
+    grp = EngineGroup(engines)
+    gro = GroupPairedRollout(grp, nets, threads, k, critic_nets=critic_of, deterministic=deterministic, seed=seed, partition=partition)
+    if partition:
+        assert sum(gro.cu_shares) == torch.cuda.get_device_properties(0).multi_processor_count and min(gro.cu_shares) >= 1
+        assert gro.cu_shares[2] > gro.cu_shares[0]                        # 21 conv positions against 6: the bigger share
+    trajs = [TrajectoryBuffer(e, T) for e in engines]
+    lps = [torch.zeros((T, 2, e.num_kitchens), device="cuda") for e in engines]
+    vas = [torch.zeros((T, 2, e.num_kitchens), device="cuda") for e in engines]
+    gro.collect(trajs, logps=lps, values=vas)
+    torch.cuda.synchronize()
+    for i, (tr, lp, va) in enumerate(want):
+        assert torch.equal(trajs[i].actions, tr.actions), f"engine {i}: actions"
+        assert torch.equal(trajs[i].obs, tr.obs) and torch.equal(trajs[i].reward, tr.reward) and torch.equal(trajs[i].done, tr.done)
+        assert torch.equal(lps[i], lp) and torch.equal(vas[i], va)
+        ora = oracle.OracleVecEnv(layout_params[names[i]], engines[i].num_kitchens)
+        acts = tr.actions.cpu().numpy()
+        for t in range(T):
+            oobs, orew, odone = ora.step(acts[t])
+            assert np.array_equal(trajs[i].obs[t + 1].cpu().numpy(), oobs) and np.array_equal(trajs[i].reward[t].cpu().numpy(), orew)
+    if not deterministic:
+        assert len(np.unique(want[0][0].actions.cpu().numpy())) == 6
+    # in-place stepping continues the draw counter where the collection stopped
+    obs, rew, done = gro.step(3)
+    assert gro.steps_done == T + 3 and obs[0].data_ptr() == engines[0].obs.data_ptr()
+    gro.close()
+    grp.close(close_engines=True)
+    for tr, _, _ in want:
+        tr.engine.close()

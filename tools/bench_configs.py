@@ -146,7 +146,50 @@ def config3_policies(n=8192, k=7, T=200, critics=True):
     return out
 
 
+def config3_group_policies(n=8192, k=7, T=200, critics=True, partition=True):
+    """Config 3 / 5 shape with the policies in the loop as 5 + 1 launches per joint step: every layout's fused policy launch side
+    by side on CU-masked streams + ONE env launch for the five engines (GroupPairedRollout / oc_group_policy_rollout)."""
+    from diverse_conventions_amd import EngineGroup, GroupPairedRollout, PackedNetworks
+    threads = n // (2 * k + 1)
+    G = 2 * k + 1
+    gen = torch.Generator().manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, generator=gen) * 0.1
+    nets, engines = [], []
+    for name in CLASSIC_LAYOUTS:
+        params = get_base_layout_params(name, 200)
+        W, H = params["width"], params["height"]
+        P = (W - 2) * (H - 2)
+        trunk = lambda: {"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+                         "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64)}
+        actors = [dict(trunk(), **{"act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)}) for _ in range(k + 1)]
+        crit = [dict(trunk(), **{"v_out.weight": r(1, 64), "v_out.bias": r(1)}) for _ in range(G)] if critics else []
+        nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=crit))
+        engines.append(OvercookedEngine(params, threads * G, 0))
+    grp = EngineGroup(engines)
+    cn = [[[k + 1 + g for g in range(G)]] * 2] * 5 if critics else None
+    ro = GroupPairedRollout(grp, nets, threads, k, critic_nets=cn, partition=partition)
+    ro.step(20)
+    sec = timed(lambda: ro.step(T))
+    kitchens = sum(e.num_kitchens for e in engines)
+    out = {"what": f"config 3 shape with policies in the loop, {k + 1} conventions in {G} segments x 5 layouts: 5 policy launches "
+                   + ("side by side on CU-masked streams" if partition else "one after the other on one stream") + " + ONE env launch per joint step"
+                   + (" (actors + critics)" if critics else " (actors)"),
+           "kitchens_total": kitchens, "us_per_joint_step": round(sec * 1e6 / T, 1), "agent_env_steps_per_s": round(2 * kitchens * T / sec),
+           "cu_shares": ro.cu_shares}
+    ro.close()
+    grp.close(close_engines=True)
+    return out
+
+
 if __name__ == "__main__":
+    if "--group-policies" in sys.argv:
+        print(json.dumps(config3_policies(critics=False)), flush=True)
+        print(json.dumps(config3_group_policies(critics=False, partition=False)), flush=True)
+        print(json.dumps(config3_group_policies(critics=False)), flush=True)
+        print(json.dumps(config3_policies(critics=True)), flush=True)
+        print(json.dumps(config3_group_policies(critics=True)), flush=True)
+        print(json.dumps(config3_group_policies(k=31, critics=True)), flush=True)            # config 5's per-GPU shape: 32 conventions, 63 segments
+        sys.exit(0)
     if "--group" in sys.argv:
         print(json.dumps(config3()), flush=True)
         print(json.dumps(config3_group()), flush=True)
