@@ -7,6 +7,7 @@ int oc_internal_fail(int code, const char *fmt, ...);      // overcooked_engine.
 struct oc_group;
 struct oc_engine;
 oc_engine *oc_internal_group_engine(oc_group *g, int i);    // overcooked_engine.hip: engine i of a group (NULL if out of range)
+int oc_internal_set_cu_budget(oc_engine *e, int cus);        // size the engine's launches for a CU-masked stream (0 = whole device)
 
 // Every launching entry point runs with the GPU that owns its buffers current, whatever the caller's (or torch's)
 // current device is, and puts the caller's device back on return: kernels are enqueued on streams of that GPU, and

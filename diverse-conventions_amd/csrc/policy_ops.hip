@@ -744,7 +744,8 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     const int n_cus = cu_budget > 0 ? std::min<int>(cu_budget, cus_of[dev]) : cus_of[dev];
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
-    a.tile_per_wg = n_tiles >= n_cus / 2 ? 1 : 0;
+    // (more tiles than CUs -- many segments on a small CU share -- would need a second round of workgroups: split evenly instead)
+    a.tile_per_wg = (n_tiles >= n_cus / 2 && n_tiles <= n_cus) ? 1 : 0;
     static const char *const env_desync = getenv("OC_POLICY_DESYNC");
     a.desync = env_desync ? atoi(env_desync) : 0;
     int grid = a.tile_per_wg ? n_tiles : n_cus;
@@ -868,50 +869,64 @@ int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void
     const OcDeviceScope on_device(oc_device_id(eng[0]));
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: cannot make device %d current", oc_device_id(eng[0]));
     hipStream_t main_stream = static_cast<hipStream_t>(stream);
-    // fork / join events: policies of step t wait for the env step of t-1; the env step waits for every policy launch
-    std::vector<hipEvent_t> pol_done(n, nullptr);
-    hipEvent_t env_done = nullptr;
-    auto cleanup = [&]() {
-        for (hipEvent_t e : pol_done) if (e) (void)hipEventDestroy(e);
-        if (env_done) (void)hipEventDestroy(env_done);
+    bool side = policy_streams != nullptr;
+    for (int i = 0; i < n && side; ++i) side = policy_streams[i] != nullptr && policy_streams[i] != stream;
+    auto policy = [&](int i, int64_t t, hipStream_t st, int budget) {
+        const oc_group_policy_slot &s = slots[i];
+        const int64_t k = in_place ? 0 : t;
+        return oc_policy_forward_cus(s.shape, s.d_packed, s.n_nets, s.d_obs + k * slot_bytes[i], rows[i], s.d_tiles, s.n_tiles,
+                                     s.d_values ? s.d_values + k * rows[i] : nullptr, s.d_actions + k * rows[i],
+                                     s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr, nullptr, sample_mode,
+                                     seed + static_cast<uint32_t>(i) * 0x9E3779B9u, counter0 + static_cast<uint32_t>(t), nullptr, nullptr, budget, st);
     };
-    bool any_side = false;
-    for (int i = 0; i < n; ++i) any_side = any_side || (policy_streams && policy_streams[i] && policy_streams[i] != stream);
-    if (any_side) {
-        hipError_t e = hipEventCreateWithFlags(&env_done, hipEventDisableTiming);
-        for (int i = 0; i < n && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&pol_done[i], hipEventDisableTiming);
-        if (e != hipSuccess) { cleanup(); return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event creation failed: %s", hipGetErrorString(e)); }
+    if (!side) {
+        // one stream: the engines' policy launches one after the other, then ONE env launch for all of them
+        std::vector<const void *> act(n);
+        std::vector<int8_t *> obs_next(n);
+        std::vector<int32_t *> rew(n), done(n);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t k = in_place ? 0 : t;
+            for (int i = 0; i < n; ++i) {
+                if (int rc = policy(i, t, main_stream, 0)) return rc;
+                act[i] = slots[i].d_actions + k * rows[i];
+                obs_next[i] = in_place ? slots[i].d_obs : slots[i].d_obs + (t + 1) * slot_bytes[i];
+                rew[i] = slots[i].d_reward + k * rows[i];
+                done[i] = slots[i].d_done + k * kitchens[i];
+            }
+            if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream)) return rc;
+        }
+        return OC_OK;
     }
-    std::vector<const void *> act(n);
-    std::vector<int8_t *> obs_next(n);
-    std::vector<int32_t *> rew(n), done(n);
+    // CU-partitioned: kitchens of different engines never interact, so every engine runs its whole rollout -- policy launch and
+    // its own env launch per step -- on its own stream and its own CUs, with no synchronisation between engines at all: one fork
+    // off the caller's stream at the start, one join at the end.  (Joining the five streams at every step for a common env launch
+    // was measured first: 1.3 ms per joint step, the cross-queue dependencies cost ten times the kernels.)
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    hipError_t he = hipSuccess;
+    for (int i = 0; i <= n && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventRecord(ev[n], main_stream);
+    for (int i = 0; i < n && he == hipSuccess; ++i) he = hipStreamWaitEvent(static_cast<hipStream_t>(policy_streams[i]), ev[n], 0);
+    if (he != hipSuccess) { cleanup(); return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: fork failed: %s", hipGetErrorString(he)); }
     int rc = OC_OK;
+    for (int i = 0; i < n; ++i) (void)oc_internal_set_cu_budget(eng[i], cu_budgets ? cu_budgets[i] : 0);
     for (int64_t t = 0; t < T && rc == OC_OK; ++t) {
         const int64_t k = in_place ? 0 : t;
-        if (any_side && hipEventRecord(env_done, main_stream) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event record failed");
-        for (int i = 0; i < n && rc == OC_OK; ++i) {
+        for (int i = 0; i < n && rc == OC_OK; ++i) {                     // interleaved, so that every stream always has work queued
             const oc_group_policy_slot &s = slots[i];
-            hipStream_t ps = (policy_streams && policy_streams[i]) ? static_cast<hipStream_t>(policy_streams[i]) : main_stream;
-            const bool side = ps != main_stream;
-            if (side && hipStreamWaitEvent(ps, env_done, 0) != hipSuccess) { rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: stream wait failed"); break; }
-            int8_t *obs_t = s.d_obs + k * slot_bytes[i];
-            int32_t *act_t = s.d_actions + k * rows[i];
-            rc = oc_policy_forward_cus(s.shape, s.d_packed, s.n_nets, obs_t, rows[i], s.d_tiles, s.n_tiles, s.d_values ? s.d_values + k * rows[i] : nullptr,
-                                       act_t, s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr, nullptr, sample_mode, seed + static_cast<uint32_t>(i) * 0x9E3779B9u,
-                                       counter0 + static_cast<uint32_t>(t), nullptr, nullptr, side && cu_budgets ? cu_budgets[i] : 0, ps);
-            if (rc == OC_OK && side && hipEventRecord(pol_done[i], ps) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: event record failed");
-            act[i] = act_t;
-            obs_next[i] = in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i];
-            rew[i] = s.d_reward + k * rows[i];
-            done[i] = s.d_done + k * kitchens[i];
+            rc = policy(i, t, static_cast<hipStream_t>(policy_streams[i]), cu_budgets ? cu_budgets[i] : 0);
+            if (rc == OC_OK)
+                rc = oc_step(eng[i], s.d_actions + k * rows[i], OC_ACT_I32, in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i],
+                             s.d_reward + k * rows[i], s.d_done + k * kitchens[i], policy_streams[i]);
         }
-        for (int i = 0; i < n && rc == OC_OK; ++i) {
-            hipStream_t ps = (policy_streams && policy_streams[i]) ? static_cast<hipStream_t>(policy_streams[i]) : main_stream;
-            if (ps != main_stream && hipStreamWaitEvent(main_stream, pol_done[i], 0) != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: stream wait failed");
-        }
-        if (rc == OC_OK) rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream);
+    }
+    for (int i = 0; i < n; ++i) (void)oc_internal_set_cu_budget(eng[i], 0);
+    for (int i = 0; i < n && he == hipSuccess; ++i) {
+        he = hipEventRecord(ev[i], static_cast<hipStream_t>(policy_streams[i]));
+        if (he == hipSuccess) he = hipStreamWaitEvent(main_stream, ev[i], 0);
     }
     cleanup();
+    if (rc == OC_OK && he != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: join failed: %s", hipGetErrorString(he));
     return rc;
 }
 

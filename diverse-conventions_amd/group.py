@@ -111,19 +111,28 @@ class EngineGroup:
 
 
 class GroupPairedRollout:
-    """Convention-paired rollout over the engines of an `EngineGroup` with the policies in the loop: per joint step every
-    engine's fused policy launch (all conventions' actors, optionally critics, both sides, every pairing segment -- what
-    `FusedPairedRollout` does for one engine) and then ONE env launch for all engines.  The policy launches of the five layouts
-    are each too small to fill an MI355X (8190 kitchens are two 32-row blocks per CU), so they run SIDE BY SIDE on CU-masked
-    streams whose shares follow each layout's policy work (`oc_cu_partition_create`), forked off and joined around the env
-    step by events; all steps are enqueued from C (`oc_group_policy_rollout`).  The reference does this as five simulators and
-    5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26, train/XD/xd_player.py:190-207).
+    """Convention-paired rollout over the engines of an `EngineGroup` with the policies in the loop: what `FusedPairedRollout`
+    does for one engine, for all of them at once, every step enqueued from C (`oc_group_policy_rollout`).  The reference does
+    this as five simulators and 5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26,
+    train/XD/xd_player.py:190-207).  Kitchens of different engines never interact, so the engines need not march in step:
+
+    partition="streams" (default): every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
+        own stream, side by side with the others, no synchronisation between engines: one fork, one join per call.
+        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 173 us per joint step, 247 us with critics; config 5's
+        (32 conventions, 63 segments, critics): 298 us (profiles/r02_bench_group_policies.log).
+    partition=False: everything on the current stream -- the policy launches one after the other, then ONE env launch for all
+        engines (`oc_group_step`): 186 / 315 us; the env launch saved is worth less than the overlap lost.
+    partition="cus": as "streams" but on CU-masked streams whose shares follow each layout's policy work
+        (`oc_cu_partition_create`).  Measured SLOWER (423 us): the masks do what they say (k bits -> k CUs, linear throughput,
+        profiles/r02_probe_cu_mask.log; two isolated launches side by side on half-device streams take 49.6 us against 91 us in a
+        row), but these policy launches already scale with the CUs they get, so a fixed split only adds fragmentation.
+    Results are identical in all three modes.
 
     nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
     critic_nets[i][side][g] as in FusedPairedRollout (or None)."""
 
     def __init__(self, group: EngineGroup, nets, threads, n_conventions: int, critic_nets=None, deterministic: bool = False, seed: int = 0,
-                 partition: bool = True):
+                 partition="streams"):
         from .fused_policy import TILE_ACT, PolicyPlan, _shape
         from .policy import segment_policy_indices
         from .sharding import pairing_segments
@@ -152,10 +161,21 @@ class GroupPairedRollout:
         self._L = L
         self._streams = (_vp * n_eng)()
         self._cus = (ctypes.c_int32 * n_eng)()
-        self._partitioned = bool(partition) and n_eng > 1
-        if self._partitioned:
+        if partition is True:
+            partition = "cus"
+        if partition not in (False, None, "streams", "cus"):
+            raise ValueError("partition must be False, 'streams' (one ordinary stream per engine) or 'cus' (CU-masked streams)")
+        self.partition = partition if (partition and n_eng > 1) else False
+        self._partitioned = self.partition == "cus"                       # CU budgets apply
+        self._side_streams = bool(self.partition)
+        self._torch_streams = None
+        if self.partition == "cus":
             shares = (ctypes.c_float * n_eng)(*[w / sum(work) for w in work])
             native.check(L.oc_cu_partition_create(group.device.index or 0, shares, n_eng, self._streams, self._cus))
+        elif self.partition == "streams":
+            self._torch_streams = [torch.cuda.Stream(group.device) for _ in range(n_eng)]
+            for i, st in enumerate(self._torch_streams):
+                self._streams[i] = st.cuda_stream
         cus_total = torch.cuda.get_device_properties(group.device).multi_processor_count
         self.plans = [PolicyPlan(nt, 2 * e.num_kitchens, rows, rows_per_tile=-(int(self._cus[i]) if self._partitioned else cus_total))
                       for i, (e, nt, rows) in enumerate(zip(group.engines, self.nets, rows_all))]
@@ -182,7 +202,7 @@ class GroupPairedRollout:
             s.d_obs, s.d_actions, s.d_action_logp, s.d_values = p(obs[i]), p(actions[i]), p(logp[i]), p(values[i])
             s.d_reward, s.d_done = p(reward[i]), p(done[i])
         native.check(self._L.oc_group_policy_rollout(
-            self.group._handle, slots, self._streams if self._partitioned else None, self._cus if self._partitioned else None, int(T),
+            self.group._handle, slots, self._streams if self._side_streams else None, self._cus if self._partitioned else None, int(T),
             1 if in_place else 0, 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
         self.steps_done += int(T)
 
@@ -208,7 +228,7 @@ class GroupPairedRollout:
         return trajs
 
     def close(self):
-        if self._partitioned and self._streams is not None:
+        if self.partition == "cus" and self._streams is not None:
             torch.cuda.synchronize(self.group.device)
             self._L.oc_cu_partition_destroy(self._streams, len(self.group))
             self._streams = None

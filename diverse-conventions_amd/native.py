@@ -30,7 +30,7 @@ SYMBOLS = [
     "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
     "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
-    "oc_import_states", "oc_import_states_checked", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
+    "oc_import_states", "oc_import_states_checked", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_set_cu_budget",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
     "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_cus", "oc_policy_uniform", "oc_policy_rollout",
     "oc_cu_partition_create", "oc_cu_partition_destroy", "oc_group_policy_rollout",
@@ -135,6 +135,7 @@ def lib():
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
     L.oc_device_id.argtypes = [vp]
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
+    L.oc_set_cu_budget.argtypes = [vp, ctypes.c_int32]
     fp = ctypes.c_float
     L.oc_gae_returns.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, i32, fp, fp, i32, vp]
     L.oc_advantage_workspace_bytes.argtypes = []

@@ -296,19 +296,24 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
                           float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                           const int32_t *d_row_select, int32_t cu_budget, void *stream);
 /* n HIP streams restricted to disjoint sets of the device's CUs, stream i getting about shares[i] / sum(shares) of them (at
- * least one; every set spread over the whole CU index range).  For launches that cannot fill the chip on their own -- one
- * layout's policies at a few thousand kitchens are two 32-row blocks per CU -- running them side by side on their own CUs
- * is what one bigger launch would do: two asymmetric_advantages policy launches of 8184 kitchens take 49.6 us together on two
- * half-device streams against 91 us one after the other (or on two unmasked streams).  out_streams: n hipStream_t (as void*),
+ * least one; every set spread over the whole CU index range).  k mask bits give k CUs and proportional throughput
+ * (tools/probes/cu_mask.hip); two isolated policy launches of 8184 asymmetric_advantages kitchens take 49.6 us together on two
+ * half-device streams against 91 us one after the other.  For the five-layout rollout a fixed split measured slower than plain
+ * streams (see oc_group_policy_rollout), so nothing in the package uses it by default.  out_streams: n hipStream_t (as void*),
  * out_cus (optional): CUs given to each.  Destroy with oc_cu_partition_destroy. */
 int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus);
 int oc_cu_partition_destroy(void *const *streams, int32_t n);
-/* T joint rollout steps of a group with the policies in the loop, enqueued from C: per step every engine's policy launch
- * (on policy_streams[i], sized for cu_budgets[i] CUs; NULL tables / entries = `stream`, whole device) followed by ONE env launch
- * for all engines (oc_group_step on `stream`); events fork the policy streams off the env step and join them before the next
- * one.  The reference's five-layout training / evaluation loop (BASELINE configs 3 and 5) as 5 + 1 launches per joint step,
- * the five running side by side.  slots[i] describes engine i exactly as oc_policy_rollout's arguments do (same buffers, same
- * in_place meaning; draw counter of step t = counter0 + t, seed offset per engine). */
+/* T rollout steps of every engine of a group with the policies in the loop, enqueued from C -- the reference's five-layout
+ * training / evaluation loop (BASELINE configs 3 and 5).  Two modes:
+ *   policy_streams == NULL: everything on `stream`; per joint step the engines' policy launches one after the other, then
+ *     ONE env launch for all of them (oc_group_step);
+ *   policy_streams given (ordinary streams, or CU-masked ones with their cu_budgets): kitchens of different engines never
+ *     interact, so engine i runs its whole rollout -- per step its policy launch and its own env launch -- on policy_streams[i],
+ *     side by side with the others and without any synchronisation between engines; `stream` is forked once at the start and
+ *     joined once at the end.  (Joining the streams at every step for a common env launch was measured first: 1.3 ms per joint
+ *     step.)  Config 3's shape: 173 us per joint step on five ordinary streams, 186 us on one stream, 423 us on CU-masked ones.
+ * slots[i] describes engine i exactly as oc_policy_rollout's arguments do (same buffers, same in_place meaning; the draw counter
+ * of step t is counter0 + t, the seed is offset per engine).  Results are identical in both modes. */
 typedef struct {
     const oc_policy_shape *shape;
     const void *d_packed;
@@ -347,6 +352,10 @@ int oc_device_id(const oc_engine *e);
  * kitchens*tiles must be a multiple of 4, so any multiple of 4 works), 64-tile staging passes per flush (1..8), persistent wavefronts per CU (1..32).
  * 0 keeps the current value. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
+
+/* Size the engine's launches for a stream that may only use `cus` of the GPU's CUs (a CU-masked stream from
+ * oc_cu_partition_create): the persistent grid becomes waves_per_cu x cus wavefronts.  0 = the whole device (default). */
+int oc_set_cu_budget(oc_engine *e, int32_t cus);
 
 /* Which kernel build serves this engine: "specialised for gfx950..." when the per-engine hiprtc build
  * succeeded at oc_create, otherwise the reason the generic ahead-of-time kernel is in use. */

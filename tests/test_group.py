@@ -255,7 +255,7 @@ def test_the_group_binding_shown_in_integration_md_runs(layout_params):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("partition", [True, False])
+@pytest.mark.parametrize("partition", ["cus", "streams", False])
 @pytest.mark.parametrize("deterministic", [True, False])
 def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deterministic, layout_params):
     """Policies in the loop over three layouts: per joint step three policy launches side by side on CU-masked streams
@@ -293,7 +293,7 @@ def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deter
     engines = make()
     grp = EngineGroup(engines)
     gro = GroupPairedRollout(grp, nets, threads, k, critic_nets=critic_of, deterministic=deterministic, seed=seed, partition=partition)
-    if partition:
+    if partition == "cus":
         assert sum(gro.cu_shares) == torch.cuda.get_device_properties(0).multi_processor_count and min(gro.cu_shares) >= 1
         assert gro.cu_shares[2] > gro.cu_shares[0]                        # 21 conv positions against 6: the bigger share
     trajs = [TrajectoryBuffer(e, T) for e in engines]

@@ -146,7 +146,7 @@ def config3_policies(n=8192, k=7, T=200, critics=True):
     return out
 
 
-def config3_group_policies(n=8192, k=7, T=200, critics=True, partition=True):
+def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"):
     """Config 3 / 5 shape with the policies in the loop as 5 + 1 launches per joint step: every layout's fused policy launch side
     by side on CU-masked streams + ONE env launch for the five engines (GroupPairedRollout / oc_group_policy_rollout)."""
     from diverse_conventions_amd import EngineGroup, GroupPairedRollout, PackedNetworks
@@ -172,7 +172,8 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition=True):
     sec = timed(lambda: ro.step(T))
     kitchens = sum(e.num_kitchens for e in engines)
     out = {"what": f"config 3 shape with policies in the loop, {k + 1} conventions in {G} segments x 5 layouts: 5 policy launches "
-                   + ("side by side on CU-masked streams" if partition else "one after the other on one stream") + " + ONE env launch per joint step"
+                   + {"cus": "+ env launches, every engine on its own CU-masked stream", "streams": "+ env launches, every engine on its own stream",
+                      False: "one after the other on one stream + ONE env launch"}[partition] + " per joint step"
                    + (" (actors + critics)" if critics else " (actors)"),
            "kitchens_total": kitchens, "us_per_joint_step": round(sec * 1e6 / T, 1), "agent_env_steps_per_s": round(2 * kitchens * T / sec),
            "cu_shares": ro.cu_shares}
@@ -184,11 +185,13 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition=True):
 if __name__ == "__main__":
     if "--group-policies" in sys.argv:
         print(json.dumps(config3_policies(critics=False)), flush=True)
-        print(json.dumps(config3_group_policies(critics=False, partition=False)), flush=True)
-        print(json.dumps(config3_group_policies(critics=False)), flush=True)
+        for mode in (False, "streams", "cus"):
+            print(json.dumps(config3_group_policies(critics=False, partition=mode)), flush=True)
         print(json.dumps(config3_policies(critics=True)), flush=True)
-        print(json.dumps(config3_group_policies(critics=True)), flush=True)
-        print(json.dumps(config3_group_policies(k=31, critics=True)), flush=True)            # config 5's per-GPU shape: 32 conventions, 63 segments
+        for mode in (False, "streams"):
+            print(json.dumps(config3_group_policies(critics=True, partition=mode)), flush=True)
+        print(json.dumps(config3_group_policies(k=31, critics=True, partition="streams")), flush=True)     # config 5's per-GPU shape
+        print(json.dumps(config3_group_policies(k=31, critics=True, partition=False)), flush=True)
         sys.exit(0)
     if "--group" in sys.argv:
         print(json.dumps(config3()), flush=True)
