@@ -35,10 +35,12 @@ def _random_nets(W, H, n_actors, n_critics, seed):
     return actors, critics
 
 
-def _check_env_against_oracle(params, traj, T, every=1):
+def _check_env_against_oracle(params, traj, T, every=1, start_state=None):
     """The recorded actions replayed through the oracle reproduce every recorded obs / reward / done of every kitchen."""
     n = traj.obs.shape[2]
     ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    if start_state is not None:
+        ora.set_state(*start_state)
     assert np.array_equal(traj.obs[0].cpu().numpy(), ora.encode())
     acts = traj.actions.cpu().numpy()
     rew, done = traj.reward.cpu().numpy(), traj.done.cpu().numpy()
@@ -187,7 +189,7 @@ def test_config5_shape_rollout_gae_minibatch(layout_params):
     k, G, T = 31, 63, 12
     threads = 8192 // G                                       # 130
     n = threads * G                                           # 8190
-    engines, oras = [], []
+    engines, oras, kept = [], [], []
     for li, name in enumerate(CLASSIC):
         params = layout_params[name]
         W, H = params["width"], params["height"]
@@ -235,6 +237,7 @@ def test_config5_shape_rollout_gae_minibatch(layout_params):
             for f, i in pos.items():
                 assert np.array_equal(b[i].cpu().numpy(), w[f]), (name, f)
         engines.append(eng)
+        kept.append((nets, actors_sd, critics_sd, critic_of, shape))
         oras.append((params, traj.actions[T - 1].clone()))
         del traj, logp, values, src, buf, got, want
     # ---- the joint env step of the five engines at this shape: one launch (n * S * 20 is not a multiple of 16 for the 5x5
@@ -250,4 +253,19 @@ def test_config5_shape_rollout_gae_minibatch(layout_params):
             ora.set_state(*st)
             oobs, orew, odone = ora.step(a.cpu().numpy())
             assert np.array_equal(o.cpu().numpy(), oobs) and np.array_equal(r.cpu().numpy(), orew) and np.array_equal(d.cpu().numpy(), odone)
+    # ---- and the whole five-layout rollout with the policies in the loop through the group API (every engine's policy + env
+    # launches on its own stream, enqueued from C): continues from the engines' current states
+    from diverse_conventions_amd import GroupPairedRollout
+    T2 = 5
+    gro = GroupPairedRollout(grp, [kp[0] for kp in kept], threads, k, critic_nets=[kp[3] for kp in kept], seed=3)
+    starts = [e.get_state() for e in engines]
+    trajs = [TrajectoryBuffer(e, T2) for e in engines]
+    lps = [torch.zeros((T2, 2, n), device="cuda") for _ in engines]
+    vas = [torch.zeros((T2, 2, n), device="cuda") for _ in engines]
+    gro.collect(trajs, logps=lps, values=vas)
+    for i, (e, (params, _)) in enumerate(zip(engines, oras)):
+        _check_env_against_oracle(params, trajs[i], T2, start_state=starts[i])
+        shim = type("Shim", (), {"segments": gro.segments[i], "threads": threads})()
+        _check_policies(shim, trajs[i], lps[i], vas[i], kept[i][1], kept[i][2], kept[i][3], T2, kept[i][4])
+    gro.close()
     grp.close(close_engines=True)
