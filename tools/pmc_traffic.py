@@ -4,7 +4,8 @@ MI355X_MICROARCH.md's HBM section prescribes):
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <round-label> [kernel] [grid]
 
-Per launch of `kernel` with `grid` threads (default: the headline engine's 2048 wavefronts): FETCH_SIZE x 2 (gfx950 counts a
+Per launch of `kernel` with `grid` threads (default: the grid it was launched with most often -- run bench.py with
+--no-secondary so that every launch of the kernel is the headline workload's): FETCH_SIZE x 2 (gfx950 counts a
 wide coalesced read at half its bytes) + WRITE_SIZE (exact for 16-byte-per-lane stores), both reported in KB."""
 import csv
 import json
@@ -17,11 +18,15 @@ from bench import algorithmic_bytes  # noqa: E402
 
 
 def mean_counter(path, counter, kernel, grid):
-    vals = []
+    rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
-            if row["Kernel_Name"] == kernel and row["Counter_Name"] == counter and int(row["Grid_Size"]) == grid:
-                vals.append(float(row["Counter_Value"]))
+            if row["Kernel_Name"] == kernel and row["Counter_Name"] == counter:
+                rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+    if not grid and rows:                               # the grid the kernel was launched with most often
+        sizes = [g for g, _ in rows]
+        grid = max(set(sizes), key=sizes.count)
+    vals = [v for g, v in rows if g == grid]
     if not vals:
         raise SystemExit(f"no {counter} rows for {kernel} with grid {grid} in {path}")
     return sum(vals) / len(vals), len(vals)
@@ -30,7 +35,7 @@ def mean_counter(path, counter, kernel, grid):
 def main():
     fetch_csv, write_csv, label = sys.argv[1:4]
     kernel = sys.argv[4] if len(sys.argv) > 4 else "oc_jit_step_i32_v16"
-    grid = int(sys.argv[5]) if len(sys.argv) > 5 else 2048 * 64
+    grid = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     fetch_kb, nf = mean_counter(fetch_csv, "FETCH_SIZE", kernel, grid)
     write_kb, nw = mean_counter(write_csv, "WRITE_SIZE", kernel, grid)
     total = int(round((2 * fetch_kb + write_kb) * 1024))
