@@ -1,0 +1,201 @@
+// oc_np_kernels.h -- kitchens with 1, 3 or 4 players (gfx950).
+//
+// The reference's Python MDP and encoder are N-player (envs/overcooked2_reimplement.py: per-viewer player slots :221-234,
+// the dish rule that only pays with exactly two players :261-263; envs/overcooked2_env.py:29 `num_players`; layouts
+// multiplayer_schelling and simple_single); its training scripts and the north star of this engine are 2-player, and the
+// hand-tuned step kernel (oc_step_body.h) is built around two players (packed positions, 20 channels = 5 dwords per tile,
+// the viewer swap).  Other player counts get this separate, plain path: one thread per kitchen for the transition, one
+// thread per (viewer, tile) for the encoding staged through LDS so that the plane bytes leave coalesced.  Same semantics,
+// same buffers and layouts with P and C = 5P + 10 generalised; bit-exact against fixtures recorded from the reference
+// (tests/golden/np_*.npz); no claim on the roofline.  "ref:" = envs/overcooked2_reimplement.py.
+//
+// State record, little endian, 16 * ceil((S + 2P + 1) / 4) bytes:
+//   uint32 tile[S]      name | onions<<8 | tomatoes<<16 | (uint8)cooking_tick<<24      (0 = empty)
+//   uint32 player[P]    position | orientation<<8
+//   uint32 held[P]      packed like a tile object
+//   uint32 timestep
+#pragma once
+
+#include "oc_step_common.h"
+
+namespace oc_np {
+
+using namespace oc_dev;
+
+constexpr int kMaxP = 4;
+
+struct NpArgs {
+    uint32_t *state;                // [N][recd]
+    const uint32_t *terrain;        // [S]
+    const void *actions;            // [P][N] i32 or i64 (NULL: encode only)
+    int act64;
+    int8_t *obs;                    // viewer v at obs + v * obs_player_stride; [N][W][H][C]
+    int64_t obs_player_stride;
+    int32_t *reward, *done;
+    int64_t n;
+    int32_t W, H, S, P, C, recd;
+    int32_t horizon, placement_rew, soup_rew;
+    int32_t rvalues[16], rtimes[16];
+    uint32_t start_pp[kMaxP];
+};
+
+__device__ __forceinline__ int np_delta(int d, int W) { return d == A_NORTH ? -W : d == A_SOUTH ? W : d == A_EAST ? 1 : d == A_WEST ? -1 : 0; }   // ref:22-32
+__device__ __forceinline__ int np_tick(uint32_t o) { return static_cast<int32_t>(o) >> 24; }
+__device__ __forceinline__ int np_count(uint32_t o) { return static_cast<int>(((o >> 8) & 0xff) + ((o >> 16) & 0xff)); }
+
+// ref:381-385 get_state_transition + the wrappers' done / reward / reset rule (envs/overcooked2_env.py:327-339,
+// pantheonrl_extension/vectorenv.py:369-370), one thread per kitchen.
+__global__ void np_step_kernel(const NpArgs a) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    uint32_t *rec = a.state + k * a.recd;
+    const int S = a.S, P = a.P, W = a.W;
+    int pos[kMaxP], ori[kMaxP], act[kMaxP];
+    uint32_t held[kMaxP];
+    for (int i = 0; i < P; ++i) {
+        const uint32_t pp = rec[S + i];
+        pos[i] = pp & 0xff; ori[i] = (pp >> 8) & 0xff;
+        held[i] = rec[S + P + i];
+        const int raw = a.act64 ? static_cast<int>(reinterpret_cast<const long long *>(a.actions)[i * a.n + k])
+                                : reinterpret_cast<const int *>(a.actions)[i * a.n + k];
+        act[i] = sanitize_action(raw);
+    }
+    int ts = static_cast<int>(rec[S + 2 * P]);
+    // ---- ref:301-354 resolve_interacts.  get_pot_states (ref:272-281) is only consulted by the dish rule, which pays only when
+    // there are exactly two players (ref:262-263): with P != 2 a dish pick-up is never rewarded.
+    int reward = 0;
+    for (int i = 0; i < P; ++i) {
+        if (act[i] != A_INTERACT) continue;
+        const int ipos = pos[i] + np_delta(ori[i], W);
+        const uint32_t terr = a.terrain[ipos];
+        uint32_t t = rec[ipos];
+        const uint32_t hname = held[i] & 0xff;
+        const bool holding = hname != O_NONE, occupied = (t & 0xff) != O_NONE;
+        if (terr == T_COUNTER) {                                                     // ref:313-319
+            if (holding && !occupied) { t = held[i]; held[i] = 0; }
+            else if (!holding && occupied) { held[i] = t; t = 0; }
+        } else if (terr == T_ONION_SRC && !holding) held[i] = kOnionObj;             // ref:320-321
+        else if (terr == T_TOMATO_SRC && !holding) held[i] = kTomatoObj;             // ref:322-323
+        else if (terr == T_DISH_SRC && !holding) held[i] = kDishObj;                 // ref:324-327 (never useful here)
+        else if (terr == T_POT && holding) {                                         // ref:331-349
+            const int time = a.rtimes[recipe_index(t)];
+            if (hname == O_DISH && occupied && np_tick(t) >= 0 && np_tick(t) >= time) {
+                held[i] = t; t = 0;
+                reward += a.soup_rew;
+            } else if (hname == O_ONION || hname == O_TOMATO) {
+                if (!occupied) t = kEmptySoup;
+                if (!(np_tick(t) >= 0 || np_count(t) == 3)) {
+                    t += hname == O_ONION ? 0x100u : 0x10000u;
+                    held[i] = 0;
+                    reward += a.placement_rew;
+                }
+                // ref:287-296,347-348: an idle soup with exactly three ingredients starts cooking
+                const int time2 = a.rtimes[recipe_index(t)];
+                const bool cooking = np_tick(t) >= 0 && np_tick(t) < time2, ready = np_tick(t) >= 0 && np_tick(t) >= time2;
+                if ((t & 0xff) == O_SOUP && !cooking && !ready && np_count(t) > 0 && np_count(t) == 3) t &= 0x00FFFFFFu;
+            }
+        } else if (terr == T_SERVING && hname == O_SOUP) {                           // ref:350-353, 283-285
+            reward += a.rvalues[recipe_index(held[i])];
+            held[i] = 0;
+        }
+        rec[ipos] = t;
+    }
+    // ---- ref:368-371 resolve_movement, ref:393-399 _move_if_direction, ref:356-366 _handle_collisions
+    int npos[kMaxP], nori[kMaxP];
+    for (int i = 0; i < P; ++i) {
+        if (act[i] == A_INTERACT) { npos[i] = pos[i]; nori[i] = ori[i]; continue; }
+        const int cand = pos[i] + np_delta(act[i], W);
+        nori[i] = act[i] == A_STAY ? ori[i] : act[i];
+        npos[i] = a.terrain[cand] != T_AIR ? pos[i] : cand;
+    }
+    bool blocked = false;
+    for (int x = 0; x < P; ++x)
+        for (int y = x + 1; y < P; ++y) blocked = blocked || npos[x] == npos[y] || (npos[x] == pos[y] && pos[x] == npos[y]);
+    for (int i = 0; i < P; ++i) {
+        if (!blocked) pos[i] = npos[i];
+        ori[i] = nori[i];
+    }
+    // ---- ref:373-379 step_environment_effects
+    ts += 1;
+    const bool is_done = ts >= a.horizon;                                            // envs/overcooked2_env.py:334
+    for (int t = 0; t < S; ++t) {
+        uint32_t o = rec[t];
+        if (is_done) { if (o) rec[t] = 0; continue; }                                // reset: ref:387-391
+        if ((o & 0xff) == O_SOUP && np_tick(o) >= 0 && np_tick(o) < a.rtimes[recipe_index(o)]) rec[t] = o + 0x01000000u;
+    }
+    for (int i = 0; i < P; ++i) {
+        rec[S + i] = is_done ? a.start_pp[i] : (static_cast<uint32_t>(pos[i]) | (static_cast<uint32_t>(ori[i]) << 8));
+        rec[S + P + i] = is_done ? 0u : held[i];
+        a.reward[i * a.n + k] = reward;                                              // sum, to every player (overcooked2_env.py:336-339)
+    }
+    rec[S + 2 * P] = is_done ? 0u : static_cast<uint32_t>(ts);
+    a.done[k] = is_done ? 1 : 0;
+}
+
+// ref:165-259 lossless_state_encoding for every viewer, output order (W, H, C) (envs/overcooked2_env.py:324).
+// Block = one viewer x kTilesPerBlock consecutive flat tiles (kitchen-major, output order inside a kitchen): a contiguous
+// byte range of that viewer's plane, built in LDS one tile per thread and written out one byte per thread, lanes contiguous.
+constexpr int kTilesPerBlock = 128;
+constexpr int kNpThreads = 256;
+
+__global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
+    __shared__ int8_t stage[kTilesPerBlock * 32];
+    const int v = blockIdx.y, S = a.S, P = a.P, C = a.C, shift = 5 * P;
+    const int64_t f0 = static_cast<int64_t>(blockIdx.x) * kTilesPerBlock, total = a.n * S;
+    const int ntiles = static_cast<int>(min(static_cast<int64_t>(kTilesPerBlock), total - f0));
+    if (threadIdx.x < ntiles) {
+        const int64_t f = f0 + threadIdx.x, k = f / S;
+        const int o = static_cast<int>(f - k * S), x = o / a.H, y = o - x * a.H, t = y * a.W + x;
+        const uint32_t *rec = a.state + k * a.recd;
+        int8_t b[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) b[c] = 0;
+        const uint32_t terr = a.terrain[t], obj = rec[t];
+        if (terr > T_AIR) b[shift + terr - 1] = 1;                                   // ref:165-171
+        const uint32_t name = obj & 0xff;
+        if (name == O_SOUP) {                                                        // ref:182-203
+            if (terr == T_POT) { b[shift + 5] = static_cast<int8_t>((obj >> 8) & 0xff); b[shift + 6] = static_cast<int8_t>(max(np_tick(obj), 0)); }
+            else b[shift + 7] = 1;
+        } else if (name == O_DISH) b[shift + 8] = 1;                                 // ref:205-207
+        else if (name == O_ONION) b[shift + 9] = 1;                                  // ref:209-211
+        int other = 1;
+        for (int i = 0; i < P; ++i) {                                                // ref:220-257
+            const uint32_t pp = rec[S + i];
+            const int slot = i == v ? 0 : other++;
+            if (static_cast<int>(pp & 0xff) != t) continue;
+            b[slot] = 1;
+            b[P + 4 * slot + ((pp >> 8) & 3)] = 1;
+            const uint32_t h = rec[S + P + i] & 0xff;
+            if (h == O_SOUP) b[shift + 7] = 1;
+            else if (h == O_DISH) b[shift + 8] = 1;
+            else if (h == O_ONION) b[shift + 9] = 1;
+        }
+        for (int c = 0; c < C; ++c) stage[threadIdx.x * C + c] = b[c];
+    }
+    __syncthreads();
+    int8_t *dst = a.obs + v * a.obs_player_stride + f0 * C;
+    for (int i = threadIdx.x; i < ntiles * C; i += kNpThreads) dst[i] = stage[i];
+}
+
+// every kitchen to the standard start state (ref:387-391)
+__global__ void np_fill_start_kernel(uint32_t *state, int64_t n, int S, int P, int recd, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= n * recd) return;
+    const int d = static_cast<int>(c % recd);
+    const uint32_t start[kMaxP] = {p0, p1, p2, p3};
+    state[c] = (d >= S && d < S + P) ? start[d - S] : 0u;
+}
+
+// per-kitchen episode control (see oc_episode_control)
+__global__ void np_episode_control_kernel(uint32_t *state, int64_t n, int S, int P, int recd, int horizon, uint32_t p0, uint32_t p1, uint32_t p2,
+                                          uint32_t p3, const int32_t *mask, const int32_t *ts) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t *rec = state + k * recd;
+    const uint32_t start[kMaxP] = {p0, p1, p2, p3};
+    if (mask && mask[k] != 0)
+        for (int d = 0; d < recd; ++d) rec[d] = (d >= S && d < S + P) ? start[d - S] : 0u;
+    if (ts) rec[S + 2 * P] = static_cast<uint32_t>(min(max(ts[k], 0), horizon - 1));
+}
+
+}  // namespace oc_np

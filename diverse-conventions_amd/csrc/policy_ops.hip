@@ -765,6 +765,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: NULL pointer or negative T");
     int64_t shp[5];
     if (int rc = oc_obs_shape(e, shp)) return rc;
+    if (shp[0] != 2 || shp[4] != OC_POLICY_C) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_rollout: the fused policy kernel reads 2-player observations");
     if (!shape || shp[2] != shape->width || shp[3] != shape->height)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: the networks' grid does not match the engine's");
     const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];

@@ -18,37 +18,52 @@ def _ptr(t):
 
 
 def pack_states(tiles, players, timestep, record_bytes):
-    """Fixture serialisation (tiles int8 [N,S,4], players int8 [N,2,6], timestep int32 [N]) ->
-    native state records uint32 [N, record_bytes/4] (layout: include/overcooked_hip.h)."""
+    """Fixture serialisation (tiles int8 [N,S,4], players int8 [N,P,6], timestep int32 [N]) ->
+    native state records uint32 [N, record_bytes/4] (layouts: include/overcooked_hip.h; P = 2 packs both players'
+    position/orientation into one word, other player counts use one word per player)."""
     tiles = np.ascontiguousarray(tiles, dtype=np.int8)
     players = np.ascontiguousarray(players, dtype=np.int8)
-    n, s = tiles.shape[0], tiles.shape[1]
+    n, s, P = tiles.shape[0], tiles.shape[1], players.shape[1]
     rec = np.zeros((n, record_bytes // 4), dtype=np.uint32)
     rec[:, :s] = tiles.view(np.uint8).view("<u4").reshape(n, s)
     pu = players.view(np.uint8).astype(np.uint32)
-    rec[:, s] = pu[:, 0, 0] | (pu[:, 0, 1] << 8) | (pu[:, 1, 0] << 16) | (pu[:, 1, 1] << 24)
-    for i in range(2):
-        rec[:, s + 1 + i] = pu[:, i, 2] | (pu[:, i, 3] << 8) | (pu[:, i, 4] << 16) | (pu[:, i, 5] << 24)
-    rec[:, s + 3] = np.asarray(timestep, dtype=np.int32).astype(np.uint32)
+    held = lambda i: pu[:, i, 2] | (pu[:, i, 3] << 8) | (pu[:, i, 4] << 16) | (pu[:, i, 5] << 24)
+    if P == 2:
+        rec[:, s] = pu[:, 0, 0] | (pu[:, 0, 1] << 8) | (pu[:, 1, 0] << 16) | (pu[:, 1, 1] << 24)
+        for i in range(2):
+            rec[:, s + 1 + i] = held(i)
+        rec[:, s + 3] = np.asarray(timestep, dtype=np.int32).astype(np.uint32)
+    else:
+        for i in range(P):
+            rec[:, s + i] = pu[:, i, 0] | (pu[:, i, 1] << 8)
+            rec[:, s + P + i] = held(i)
+        rec[:, s + 2 * P] = np.asarray(timestep, dtype=np.int32).astype(np.uint32)
     return rec
 
 
-def unpack_states(rec, s):
+def unpack_states(rec, s, num_players=2):
     """Inverse of pack_states."""
     rec = np.ascontiguousarray(rec, dtype=np.uint32)
-    n = rec.shape[0]
+    n, P = rec.shape[0], num_players
     tiles = rec[:, :s].copy().view(np.uint8).reshape(n, s, 4).view(np.int8)
-    players = np.zeros((n, 2, 6), dtype=np.uint8)
-    posor = rec[:, s]
-    players[:, 0, 0] = posor & 0xFF
-    players[:, 0, 1] = (posor >> 8) & 0xFF
-    players[:, 1, 0] = (posor >> 16) & 0xFF
-    players[:, 1, 1] = (posor >> 24) & 0xFF
-    for i in range(2):
-        held = rec[:, s + 1 + i]
+    players = np.zeros((n, P, 6), dtype=np.uint8)
+    if P == 2:
+        posor = rec[:, s]
+        players[:, 0, 0] = posor & 0xFF
+        players[:, 0, 1] = (posor >> 8) & 0xFF
+        players[:, 1, 0] = (posor >> 16) & 0xFF
+        players[:, 1, 1] = (posor >> 24) & 0xFF
+        held_at, ts_at = s + 1, s + 3
+    else:
+        for i in range(P):
+            players[:, i, 0] = rec[:, s + i] & 0xFF
+            players[:, i, 1] = (rec[:, s + i] >> 8) & 0xFF
+        held_at, ts_at = s + P, s + 2 * P
+    for i in range(P):
+        held = rec[:, held_at + i]
         for b in range(4):
             players[:, i, 2 + b] = (held >> (8 * b)) & 0xFF
-    return tiles, players.view(np.int8), rec[:, s + 3].astype(np.int32)
+    return tiles, players.view(np.int8), rec[:, ts_at].astype(np.int32)
 
 
 class OvercookedEngine:
@@ -68,6 +83,7 @@ class OvercookedEngine:
         self.width, self.height = params["width"], params["height"]
         self.size = self.width * self.height
         self.num_players = params["num_players"]
+        self.channels = 5 * self.num_players + 10        # 20 for the 2-player kitchens every tuned path is built for
         self.device = torch.device("cuda", device_index)
         handle = ctypes.c_void_p()
         native.check(L.oc_create(ctypes.byref(native.make_params(params)), self.num_kitchens, device_index,
@@ -77,8 +93,8 @@ class OvercookedEngine:
         self.record_bytes = int(L.oc_state_record_bytes(handle))
         n = self.num_kitchens
         with torch.cuda.device(self.device):
-            self.obs = torch.zeros((2, n, self.width, self.height, CHANNELS), dtype=torch.int8, device=self.device)
-            self.reward = torch.zeros((2, n), dtype=torch.int32, device=self.device)
+            self.obs = torch.zeros((self.num_players, n, self.width, self.height, self.channels), dtype=torch.int8, device=self.device)
+            self.reward = torch.zeros((self.num_players, n), dtype=torch.int32, device=self.device)
             self.done = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.observe()
 
@@ -105,8 +121,8 @@ class OvercookedEngine:
             a = a.to(self.device)
         if a.dtype not in (torch.int32, torch.int64):
             a = a.to(torch.int32)
-        if a.numel() != 2 * self.num_kitchens:
-            raise ValueError(f"actions must have {2 * self.num_kitchens} elements ([P, N] or [P, N, 1]), got {tuple(a.shape)}")
+        if a.numel() != self.num_players * self.num_kitchens:
+            raise ValueError(f"actions must have {self.num_players * self.num_kitchens} elements ([P, N] or [P, N, 1]), got {tuple(a.shape)}")
         if not a.is_contiguous():
             a = a.contiguous()
         return a, (native.OC_ACT_I64 if a.dtype == torch.int64 else native.OC_ACT_I32)
@@ -158,8 +174,8 @@ class OvercookedEngine:
         """`steps` consecutive launches enqueued from C.  actions [T_act, P, N] are cycled.
         obs/reward/done may carry a leading time axis of length `steps` (time-major trajectory
         buffers, written in place) or be single-step buffers that are overwritten."""
-        if actions.dim() < 3 or actions[0].numel() != 2 * self.num_kitchens:
-            raise ValueError(f"rollout actions must be [T_act, P, N] with P*N = {2 * self.num_kitchens}")
+        if actions.dim() < 3 or actions[0].numel() != self.num_players * self.num_kitchens:
+            raise ValueError(f"rollout actions must be [T_act, P, N] with P*N = {self.num_players * self.num_kitchens}")
         t_act = actions.shape[0]
         flat = actions if actions.device == self.device else actions.to(self.device)
         if flat.dtype not in (torch.int32, torch.int64):
@@ -228,7 +244,7 @@ class OvercookedEngine:
         """records: uint8/int32 device tensor holding n native state records -> int8 [P, n, W, H, C]."""
         n = records.numel() * records.element_size() // self.record_bytes
         if obs is None:
-            obs = torch.empty((2, n, self.width, self.height, CHANNELS), dtype=torch.int8, device=self.device)
+            obs = torch.empty((self.num_players, n, self.width, self.height, self.channels), dtype=torch.int8, device=self.device)
         native.check(self._L.oc_encode_states(self._handle, _ptr(records), n, _ptr(obs), self._stream()))
         return obs
 
@@ -241,7 +257,7 @@ class OvercookedEngine:
         """Featurise `records` (n native state records) into kitchens [kitchen_offset, kitchen_offset+n) of a
         larger int8 [P, N_total, W, H, C] tensor (one launch, no staging copy)."""
         n = records.numel() * records.element_size() // self.record_bytes
-        per_kitchen = self.size * CHANNELS
+        per_kitchen = self.size * self.channels
         if obs_global.dim() != 5 or not obs_global.is_contiguous() or kitchen_offset + n > obs_global.shape[1]:
             raise ValueError("obs_global must be a contiguous [P, N_total, W, H, C] tensor that holds the block")
         dst = obs_global.data_ptr() + kitchen_offset * per_kitchen
@@ -253,7 +269,7 @@ class OvercookedEngine:
         """Featurise T blocks of n records (`records` [T, n, rec/4], block t possibly strided) into kitchens
         [kitchen_offset, kitchen_offset+n) of every time slot of an int8 [T, P, N_total, W, H, C] tensor: one launch."""
         T, n = records.shape[0], records.shape[1]
-        per_kitchen = self.size * CHANNELS
+        per_kitchen = self.size * self.channels
         if (obs_global.dim() != 6 or not obs_global.is_contiguous() or obs_global.shape[0] != T
                 or kitchen_offset + n > obs_global.shape[2]):
             raise ValueError("obs_global must be a contiguous [T, P, N_total, W, H, C] tensor that holds the block")
@@ -312,7 +328,7 @@ class OvercookedEngine:
         count = self.num_kitchens - first if count is None else count
         rec = np.empty((count, self.record_bytes // 4), dtype=np.uint32)
         native.check(self._L.oc_get_state(self._handle, first, count, rec.ctypes.data_as(ctypes.c_void_p)))
-        return unpack_states(rec, self.size)
+        return unpack_states(rec, self.size, self.num_players)
 
     def set_state(self, tiles, players, timestep, first=0):
         rec = pack_states(tiles, players, timestep, self.record_bytes)

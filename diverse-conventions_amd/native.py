@@ -58,7 +58,7 @@ class OcLayoutParams(ctypes.Structure):
         ("placement_in_pot_rew", ctypes.c_int32), ("dish_pickup_rew", ctypes.c_int32),
         ("soup_pickup_rew", ctypes.c_int32), ("horizon", ctypes.c_int32),
         ("recipe_values", ctypes.c_int32 * 16), ("recipe_times", ctypes.c_int32 * 16),
-        ("start_player_x", ctypes.c_int32 * 2), ("start_player_y", ctypes.c_int32 * 2),
+        ("start_player_x", ctypes.c_int32 * 4), ("start_player_y", ctypes.c_int32 * 4),       # OC_MAX_PLAYERS
         ("terrain", ctypes.c_int32 * 256),
     ]
 
@@ -221,8 +221,8 @@ def jit_compile_check_group(params_list, kitchens_list, num_cus=256, arch="gfx95
 
 def make_params(params):
     """dict from get_base_layout_params -> struct oc_layout_params"""
-    if params["num_players"] > 2:
-        raise OvercookedNativeError(-2, f"only 2-player kitchens are supported (got {params['num_players']})")
+    if not 1 <= params["num_players"] <= 4:
+        raise OvercookedNativeError(-2, f"1..4 players are supported (got {params['num_players']})")
     S = params["width"] * params["height"]
     if S > 255 or len(params["terrain"]) != S:
         raise OvercookedNativeError(-2, f"grid {params['width']}x{params['height']} outside 1..255 tiles")

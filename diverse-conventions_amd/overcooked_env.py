@@ -8,7 +8,7 @@ task graph plus ~10 torch gather/scatter kernels.
 import numpy as np
 import torch
 
-from .engine import CHANNELS, NUM_ACTIONS, OvercookedEngine
+from .engine import NUM_ACTIONS, OvercookedEngine
 from .layouts import get_base_layout_params
 from .vector_api import VectorMultiAgentEnv, VectorObservation
 
@@ -51,7 +51,8 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         self.static_dones = self.sim.done               # int32 [N]
         self.static_action_mask = torch.ones((num_envs, NUM_ACTIONS), dtype=torch.bool, device=env_device)
         self.static_active = torch.ones((num_envs,), dtype=torch.bool, device=env_device)
-        self.obs_size = self.size * CHANNELS
+        self.channels = 5 * self.num_players + 10        # envs/overcooked2_env.py:49,97
+        self.obs_size = self.size * self.channels
         self.state_size = self.obs_size
         self.infos = [{}] * self.num_envs
 
@@ -61,7 +62,7 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         self.n_reset()
 
     def _setup_observation_space(self):
-        return MultiBinary(np.array([self.width, self.height, CHANNELS]))
+        return MultiBinary(np.array([self.width, self.height, self.channels]))
 
     def to_torch(self, a):
         return a.to(self.device)

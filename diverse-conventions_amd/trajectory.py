@@ -8,7 +8,7 @@ slot t+1 of an int8 trajectory tensor; nothing is copied and the dtype stays int
 """
 import torch
 
-from .engine import CHANNELS, OvercookedEngine
+from .engine import OvercookedEngine
 
 
 class TrajectoryBuffer:
@@ -18,9 +18,10 @@ class TrajectoryBuffer:
     def __init__(self, engine: OvercookedEngine, length: int, store_states: bool = False):
         self.engine, self.T = engine, int(length)
         n, dev = engine.num_kitchens, engine.device
-        self.obs = torch.zeros((self.T + 1, 2, n, engine.width, engine.height, CHANNELS), dtype=torch.int8, device=dev)
-        self.actions = torch.zeros((self.T, 2, n), dtype=torch.int32, device=dev)
-        self.reward = torch.zeros((self.T, 2, n), dtype=torch.int32, device=dev)
+        P = self.P = engine.num_players
+        self.obs = torch.zeros((self.T + 1, P, n, engine.width, engine.height, engine.channels), dtype=torch.int8, device=dev)
+        self.actions = torch.zeros((self.T, P, n), dtype=torch.int32, device=dev)
+        self.reward = torch.zeros((self.T, P, n), dtype=torch.int32, device=dev)
         self.done = torch.zeros((self.T, n), dtype=torch.int32, device=dev)
         self.records = (torch.zeros((self.T + 1, n, engine.record_bytes // 4), dtype=torch.int32, device=dev)
                         if store_states else None)
@@ -40,7 +41,7 @@ class TrajectoryBuffer:
         if self.t >= self.T:
             raise IndexError("trajectory is full: call after_update() or start()")
         t = self.t
-        self.actions[t].copy_(actions.reshape(2, -1))
+        self.actions[t].copy_(actions.reshape(self.P, -1))
         self.engine.step(self.actions[t], obs=self.obs[t + 1], reward=self.reward[t], done=self.done[t])
         if self.records is not None:
             self.engine.export_states(out=self.records[t + 1])
@@ -53,7 +54,7 @@ class TrajectoryBuffer:
         if self.records is not None:
             raise ValueError("rollout() does not record states; use step()")
         self.start()
-        self.actions.copy_(actions.reshape(self.T, 2, -1))
+        self.actions.copy_(actions.reshape(self.T, self.P, -1))
         self.engine.rollout_fused(self.T, actions=self.actions, obs=self.obs[1:], reward=self.reward, done=self.done)
         self.t = self.T
         return self

@@ -18,8 +18,11 @@
  *     device synchronisation except in oc_create / oc_destroy / oc_get_state / oc_set_state.
  *   - one handle = one GPU = one caller thread at a time (same contract as the reference,
  *     SURVEY.md 8(b) "threading").  Several handles per process are fine.
- *   - P = 2 players (the reference's encoder and dish-usefulness rule are 2-player; other player
- *     counts return OC_ERR_UNSUPPORTED), S = width*height <= 255 tiles, C = 5P+10 = 20 channels.
+ *   - P = 2 players is the tuned path (the reference's training scripts and its dish-usefulness rule are 2-player): C = 5P+10
+ *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
+ *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a plain, separate kernel pair with the same buffers and
+ *     semantics, C = 5P+10 channels; oc_rollout_fused, oc_encode_trajectory, oc_import_states_checked, groups and the fused
+ *     policy kernel are 2-player only and return OC_ERR_UNSUPPORTED for them.  S = width*height <= 255 tiles.
  *
  * Tensor layouts (identical in meaning to the reference's exported tensors)
  *   actions  int32 or int64 [P][N]        ref: action_tensor   i32[P,N,1]   (mgr.cpp:225-229)
@@ -37,6 +40,8 @@
  *   uint32 held[2]     same packing as a tile object
  *   uint32 timestep
  *   zero padding to a multiple of 16 bytes
+ * With P != 2 players: tile[S], uint32 player[P] = position | orientation<<8, uint32 held[P], uint32 timestep, padding
+ * (16 * ceil((S + 2P + 1) / 4) bytes).
  */
 #ifndef OVERCOOKED_HIP_H
 #define OVERCOOKED_HIP_H
@@ -48,14 +53,14 @@ extern "C" {
 #endif
 
 #define OC_MAX_TILES 255
-#define OC_MAX_PLAYERS 2
+#define OC_MAX_PLAYERS 4
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 2
+#define OC_ABI_VERSION 3
 
 typedef enum {
     OC_OK = 0,
     OC_ERR_INVALID_ARG = -1,   /* NULL pointer, bad size, misaligned buffer, terrain code out of range ... */
-    OC_ERR_UNSUPPORTED = -2,   /* num_players != 2, too many tiles/pots, cook time > 127 */
+    OC_ERR_UNSUPPORTED = -2,   /* more than 4 players, too many tiles/pots, cook time > 127, a 2-player-only call on another count */
     OC_ERR_HIP = -3,           /* a HIP runtime call failed; text in oc_last_error() */
     OC_ERR_NO_DEVICE = -4      /* no usable GPU: the engine never falls back to the CPU */
 } oc_status;

@@ -22,12 +22,12 @@ def test_library_exports_every_declared_symbol():
     assert sorted(native.SYMBOLS) == declared
     for name in declared:
         assert getattr(L, name) is not None, name
-    assert L.oc_abi_version() == 2
+    assert L.oc_abi_version() == 3
 
 
 def test_layout_struct_matches_header():
-    # 7 scalars + 2x16 recipe tables + 2x2 start coordinates + 256 terrain codes, all int32
-    assert ctypes.sizeof(native.OcLayoutParams) == 4 * (7 + 32 + 4 + 256)
+    # 7 scalars + 2x16 recipe tables + 2x4 start coordinates (OC_MAX_PLAYERS) + 256 terrain codes, all int32
+    assert ctypes.sizeof(native.OcLayoutParams) == 4 * (7 + 32 + 8 + 256)
 
 
 def _create(params, n=8):
@@ -55,9 +55,9 @@ def test_error_codes_not_crashes():
     rc, msg = _create(unwalled)
     assert rc == -1 and "walled" in msg
     p = native.make_params(good)
-    p.num_players = 3
+    p.num_players = 5
     rc, msg = _create(p)
-    assert rc == -2 and "2-player" in msg
+    assert rc == -2 and "1..4 players" in msg
     slow = dict(good, recipe_times=[200] * 16)
     rc, msg = _create(slow)
     assert rc == -2 and "recipe_times" in msg
@@ -112,4 +112,4 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
-    assert out[0] == "-2" and "2-player" in out[1] and out[2] == "2" and out[3] == "0"
+    assert out[0] == "-2" and "players" in out[1] and out[2] == "3" and out[3] == "0"

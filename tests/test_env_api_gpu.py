@@ -80,7 +80,7 @@ def test_constructor_errors():
     with pytest.raises(FileNotFoundError):
         OvercookedMadrona("no_such_kitchen", 4, 0)
     with pytest.raises(OvercookedNativeError):
-        OvercookedMadrona("multiplayer_schelling", 4, 0)      # 4 players: unsupported, reported not crashed
+        OvercookedMadrona("multiplayer_schelling", 0, 0)      # no kitchens: reported, not crashed
 
 
 def test_fused_partner_agent_in_the_reference_loop(layout_params):

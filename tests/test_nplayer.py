@@ -1,0 +1,128 @@
+"""Kitchens with 1, 3 and 4 players (the reference's Python MDP and encoder are N-player: envs/overcooked2_reimplement.py
+:221-234, :261-263; envs/overcooked2_env.py:29 `num_players`; layouts multiplayer_schelling, simple_single).  The HIP engine
+runs them on a plain kernel pair (csrc/oc_np_kernels.h); parity bar as everywhere: bit-exact against fixtures recorded from the
+reference (tests/golden/np_*.npz, make_golden_nplayer.py) and against the oracle on batches."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files, load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+NP_FIXTURES = golden_files("np_random_") + golden_files("np_guided_")
+
+
+def nplayer_params():
+    with open(os.path.join(GOLDEN, "layout_params_nplayer.json")) as f:
+        return json.load(f)
+
+
+def case_of(path):
+    return os.path.basename(path)[:-4].split("_", 2)[2]
+
+
+@pytest.mark.parametrize("path", NP_FIXTURES, ids=[os.path.basename(p)[:-4] for p in NP_FIXTURES])
+def test_hip_replays_reference_nplayer_fixture(path):
+    from diverse_conventions_amd import OvercookedEngine
+    rec = load_golden(path)
+    params = nplayer_params()[case_of(path)]
+    P = params["num_players"]
+    eng = OvercookedEngine(params, 1, 0)
+    assert tuple(eng.obs.shape) == (P, 1, params["width"], params["height"], 5 * P + 10) and f"{P}-player" in eng.kernel_build_info
+    eng.set_state(rec["init_tiles"][None], rec["init_players"][None], rec["init_timestep"][None])
+    assert np.array_equal(eng.observe().cpu().numpy()[:, 0], rec["init_obs"])
+    T = len(rec["actions"])
+    acts = torch.from_numpy(rec["actions"].astype(np.int32)).cuda().reshape(T, P, 1)
+    for t in range(T):
+        obs, rew, done = eng.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy()[:, 0], rec["obs"][t]), f"step {t}: obs"
+        assert np.all(rew.cpu().numpy()[:, 0] == rec["reward"][t]) and int(done.cpu()[0]) == int(rec["done"][t]), f"step {t}"
+        tiles, players, ts = eng.get_state()
+        assert np.array_equal(tiles[0], rec["tiles"][t]) and np.array_equal(players[0], rec["players"][t]) and int(ts[0]) == int(rec["timestep"][t])
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["schelling4", "schelling3", "single"])
+def test_hip_vs_oracle_nplayer_batch(case):
+    """1003 kitchens (ragged blocks), 430 steps over two horizon resets, per-kitchen streams built from the fixture's guided
+    stream with random substitutions; int64 [P, N, 1] actions on odd steps."""
+    from diverse_conventions_amd import OvercookedEngine
+    params = nplayer_params()[case]
+    P, n, T = params["num_players"], 1003, 430
+    g = load_golden(os.path.join(GOLDEN, f"np_guided_{case}.npz"))["actions"]
+    rng = np.random.default_rng(4)
+    base = np.broadcast_to(g[:T, :, None], (T, P, n))
+    acts = np.where(rng.random((T, 1, n)) < 0.85, base, rng.integers(0, 6, size=(T, P, n))).astype(np.int32)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng = OvercookedEngine(params, n, 0)
+    assert np.array_equal(eng.observe().cpu().numpy(), ora.encode())
+    dacts = torch.from_numpy(acts).cuda()
+    total = 0
+    for t in range(T):
+        a = dacts[t].to(torch.int64).unsqueeze(-1) if t % 2 else dacts[t]
+        obs, rew, done = eng.step(a)
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone), f"step {t}"
+        assert np.array_equal(obs.cpu().numpy(), oobs), f"step {t}: obs"
+        total += int(orew[0].sum())
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    assert total > 0 and int(ora.timestep[0]) == T - 400
+    eng.close()
+
+
+def test_four_player_drop_in_env_and_buffers():
+    """OvercookedMadrona("multiplayer_schelling", ...) as the reference constructs it (envs/overcooked2_env.py:29): three partner
+    agents, observations (N, 7, 7, 30); the time-major TrajectoryBuffer, per-kitchen episode control and state export / import /
+    re-featurisation work for any player count; the 2-player-only entry points refuse politely."""
+    from diverse_conventions_amd import EngineGroup, OvercookedEngine, OvercookedMadrona, RandomVectorAgent, TrajectoryBuffer
+    from diverse_conventions_amd.native import OvercookedNativeError
+    params = nplayer_params()["schelling4"]
+    n, T = 64, 30
+    rng = np.random.default_rng(1)
+    acts = rng.integers(0, 6, size=(T, 4, n, 1))
+    dacts = torch.from_numpy(acts).cuda()
+    env = OvercookedMadrona("multiplayer_schelling", n, 0, debug_compile=False)
+    assert env.n_players == 4 and tuple(env.observation_space.shape) == (7, 7, 30)
+    step_no = [0]
+    for pl in (1, 2, 3):
+        env.add_partner_agent(RandomVectorAgent(lambda pl=pl: dacts[step_no[0], pl]), player_num=pl)
+    ora = oracle.OracleVecEnv(params, n)
+    vobs = env.reset()
+    assert vobs.obs.shape == (n, 7, 7, 30) and np.array_equal(vobs.obs.cpu().numpy(), ora.encode()[0])
+    for t in range(T):
+        step_no[0] = t
+        vobs, rew, done, _ = env.step(dacts[t, 0])
+        oobs, orew, odone = ora.step(acts[t, :, :, 0])
+        assert np.array_equal(vobs.obs.cpu().numpy(), oobs[0]) and np.array_equal(rew.cpu().numpy(), orew[0])
+    env.close()
+    eng = OvercookedEngine(params, n, 0)
+    buf = TrajectoryBuffer(eng, T, store_states=True)
+    ora = oracle.OracleVecEnv(params, n)
+    for t in range(T):
+        buf.step(dacts[t])
+        ora.step(acts[t, :, :, 0])
+    assert buf.obs.shape == (T + 1, 4, n, 7, 7, 30) and np.array_equal(buf.obs[T].cpu().numpy(), ora.encode())
+    assert np.array_equal(eng.encode_states(buf.records[T]).cpu().numpy(), ora.encode())       # re-featurised from the compact records
+    other = OvercookedEngine(params, n, 0)
+    other.import_states(eng.export_states())
+    assert torch.equal(other.observe(), buf.obs[T])
+    mask = torch.zeros(n, dtype=torch.int32, device="cuda"); mask[::2] = 1
+    eng.episode_control(reset_mask=mask, timesteps=torch.full((n,), 195, dtype=torch.int32, device="cuda"))
+    tiles, players, ts = eng.get_state()
+    start = oracle.OracleVecEnv(params, 1).get_state()
+    assert np.array_equal(tiles[0], start[0][0]) and np.array_equal(players[0], start[1][0]) and np.all(ts == 195)
+    _, _, d = eng.rollout(dacts[:5, :, :, 0].to(torch.int32).contiguous(), 5)
+    assert int(d.sum()) == n                                          # every kitchen reached the horizon at the fifth step
+    with pytest.raises(OvercookedNativeError, match="2-player"):
+        eng.rollout_fused(3, seed=1)
+    with pytest.raises(OvercookedNativeError, match="2-player"):
+        EngineGroup([eng, other])
+    with pytest.raises(OvercookedNativeError, match="2-player"):
+        eng.import_states_checked(eng.export_states())
+    eng.close(); other.close()

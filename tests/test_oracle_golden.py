@@ -151,3 +151,49 @@ def test_python_oracle_on_arbitrary_states(path, layout_params):
         assert done == bool(z["done"][i]) and np.array_equal(np.array(tiles, np.int8), z["n_tiles"][i]), i
         assert np.array_equal(np.array(players, np.int16).astype(np.int8), z["n_players"][i]) and ts == int(z["n_timestep"][i]), i
         assert np.array_equal(np.array(obs, np.int8), z["obs"][i]), i
+
+
+# ---------------------------------------------------------------------------------------- 1, 3 and 4 players
+NP_FIXTURES = golden_files("np_random_") + golden_files("np_guided_")
+
+
+def nplayer_params():
+    with open(os.path.join(GOLDEN, "layout_params_nplayer.json")) as f:
+        return json.load(f)
+
+
+def np_case_of(path):
+    return os.path.basename(path)[:-4].split("_", 2)[2]
+
+
+@pytest.mark.parametrize("path", NP_FIXTURES, ids=[os.path.basename(p)[:-4] for p in NP_FIXTURES])
+def test_oracle_replays_nplayer_fixture(path):
+    """The oracle is N-player like the reference's Python MDP (per-viewer player slots ref:221-234, the 2-player-only dish
+    rule ref:261-263): fixtures recorded from the reference on multiplayer_schelling (4 and 3 players) and simple_single."""
+    rec = load_golden(path)
+    params = nplayer_params()[np_case_of(path)]
+    P = params["num_players"]
+    assert rec["obs"].shape[1] == P and rec["obs"].shape[-1] == 5 * P + 10
+    env = oracle.OracleVecEnv(params, 1)
+    env.set_state(rec["init_tiles"][None], rec["init_players"][None], rec["init_timestep"][None])
+    assert np.array_equal(env.encode()[:, 0], rec["init_obs"])
+    tiles, players, ts = rec["init_tiles"], rec["init_players"], int(rec["init_timestep"])
+    for t, a in enumerate(rec["actions"]):
+        _, _, _, r = oracle.transition(params, tiles, players, ts, a)
+        assert np.array_equal(r, rec["reward_per_player"][t]), f"step {t}: per-player reward"
+        obs, reward, done = env.step(a.reshape(-1, 1))
+        assert int(done[0]) == int(rec["done"][t]) and np.all(reward[:, 0] == rec["reward"][t]), f"step {t}"
+        tiles, players, ts = (x[0] for x in env.get_state())
+        ts = int(ts)
+        assert np.array_equal(tiles, rec["tiles"][t]) and np.array_equal(players, rec["players"][t]) and ts == int(rec["timestep"][t])
+        assert np.array_equal(obs[:, 0], rec["obs"][t]), f"step {t}: obs"
+
+
+def test_own_layout_parser_matches_reference_for_nplayer_layouts():
+    from diverse_conventions_amd import get_base_layout_params
+    want = nplayer_params()
+    for case, (layout, maxp) in {"schelling4": ("multiplayer_schelling", None), "schelling3": ("multiplayer_schelling", 3),
+                                 "single": ("simple_single", None)}.items():
+        got = get_base_layout_params(layout, 200, max_num_players=maxp)
+        for k, v in want[case].items():
+            assert (list(got[k]) if isinstance(v, list) else got[k]) == v, (case, k)
