@@ -27,6 +27,7 @@ constexpr int kMaxP = 4;
 struct NpArgs {
     uint32_t *state;                // [N][recd]
     const uint32_t *terrain;        // [S]
+    const uint32_t *out_tab2;       // [2S]: low byte of entry 2*o = state tile index of output tile o = x*H + y
     const void *actions;            // [P][N] i32 or i64 (NULL: encode only)
     int act64;
     int8_t *obs;                    // viewer v at obs + v * obs_player_stride; [N][W][H][C]
@@ -139,17 +140,19 @@ constexpr int kTilesPerBlock = 128;
 constexpr int kNpThreads = 256;
 
 __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
-    __shared__ int8_t stage[kTilesPerBlock * 32];
+    __shared__ __attribute__((aligned(16))) int8_t stage[kTilesPerBlock * 32];
     const int v = blockIdx.y, S = a.S, P = a.P, C = a.C, shift = 5 * P;
     const int64_t f0 = static_cast<int64_t>(blockIdx.x) * kTilesPerBlock, total = a.n * S;
     const int ntiles = static_cast<int>(min(static_cast<int64_t>(kTilesPerBlock), total - f0));
+    for (int i = threadIdx.x; i < kTilesPerBlock * 32 / 4; i += kNpThreads) reinterpret_cast<uint32_t *>(stage)[i] = 0u;
+    __syncthreads();
     if (threadIdx.x < ntiles) {
-        const int64_t f = f0 + threadIdx.x, k = f / S;
-        const int o = static_cast<int>(f - k * S), x = o / a.H, y = o - x * a.H, t = y * a.W + x;
-        const uint32_t *rec = a.state + k * a.recd;
-        int8_t b[32];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) b[c] = 0;
+        // (flat tile indices fit 32 bits -- the host checks -- so this is one 32-bit division per thread; the (x, y) of an
+        // output tile comes from the table, not from two more)
+        const uint32_t f = static_cast<uint32_t>(f0) + threadIdx.x, k = f / static_cast<uint32_t>(S);
+        const int o = static_cast<int>(f - k * S), t = static_cast<int>(a.out_tab2[2 * o] & 0xff);
+        const uint32_t *rec = a.state + static_cast<int64_t>(k) * a.recd;
+        int8_t *b = stage + threadIdx.x * C;                                         // this tile's C bytes, already zero
         const uint32_t terr = a.terrain[t], obj = rec[t];
         if (terr > T_AIR) b[shift + terr - 1] = 1;                                   // ref:165-171
         const uint32_t name = obj & 0xff;
@@ -170,11 +173,19 @@ __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
             else if (h == O_DISH) b[shift + 8] = 1;
             else if (h == O_ONION) b[shift + 9] = 1;
         }
-        for (int c = 0; c < C; ++c) stage[threadIdx.x * C + c] = b[c];
     }
     __syncthreads();
+    // the block's bytes are one contiguous range of the viewer's plane: 16 bytes per lane where the plane is dword aligned (a
+    // 16-byte store needs no more on gfx950, see store16), single bytes otherwise and for the last few
     int8_t *dst = a.obs + v * a.obs_player_stride + f0 * C;
-    for (int i = threadIdx.x; i < ntiles * C; i += kNpThreads) dst[i] = stage[i];
+    const int nbytes = ntiles * C;
+    int done_bytes = 0;
+    if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        const int n16 = nbytes >> 4;
+        for (int i = threadIdx.x; i < n16; i += kNpThreads) store16<SM_PLAIN>(dst + 16 * i, reinterpret_cast<const uint4 *>(stage)[i]);
+        done_bytes = n16 << 4;
+    }
+    for (int i = done_bytes + threadIdx.x; i < nbytes; i += kNpThreads) dst[i] = stage[i];
 }
 
 // every kitchen to the standard start state (ref:387-391)
