@@ -162,7 +162,7 @@ int oc_encode_trajectory(oc_engine *e, const void *d_states, int64_t n, int64_t 
  * and results per engine are exactly those of oc_step / oc_observe.  Without a usable hiprtc the calls fall back to one
  * launch per engine, same results (oc_group_build_info says which). */
 int oc_group_create(oc_engine *const *engines, int32_t n_engines, oc_group **out);
-int oc_group_destroy(oc_group *g);                    /* the engines stay alive and belong to the caller */
+int oc_group_destroy(oc_group *g);                    /* the engines belong to the caller: they stay alive, and must outlive the group */
 int32_t oc_group_size(const oc_group *g);
 int oc_group_step(oc_group *g, const void *const *d_actions, int action_dtype, int8_t *const *d_obs, int32_t *const *d_reward,
                   int32_t *const *d_done, void *stream);
