@@ -6,4 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from bench_fused_policy import run
-print(run("cramped_room", 4096, 7, iters=3, with_torch=False))
+layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+print(run(layout, threads, 7, iters=3, with_torch=False))
