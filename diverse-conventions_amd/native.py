@@ -20,6 +20,11 @@ KERNEL_BODY = os.path.join(CSRC, "oc_step_body.h")
 KERNEL_SRC_INC = os.path.join(CSRC, "oc_step_kernel_src.inc")     # generated: both headers as C++ raw strings
 INCLUDE = os.path.join(REPO_ROOT, "include")
 
+# hiprtc code objects are cached on disk (overcooked_engine.hip: jit_compile_text).  From Python the cache lives in-tree, next to
+# the built library -- like liboc_hip.so it is git-ignored but travels with a snapshot of the repo, so a fresh box does not
+# recompile what this checkout has compiled already; the file names hash program text, headers, target and compiler version.
+os.environ.setdefault("OC_JIT_CACHE", os.path.join(REPO_ROOT, ".oc_jit_cache"))
+
 OC_OK = 0
 OC_ACT_I32, OC_ACT_I64 = 0, 1
 STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", -3: "OC_ERR_HIP", -4: "OC_ERR_NO_DEVICE"}
