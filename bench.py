@@ -286,7 +286,7 @@ def main():
           torch.cuda.synchronize()
           step_us = (time.perf_counter() - t1) / psteps * 1e6
           rows = 2 * eng2.num_kitchens
-          cycles = rows / 32 * (P * (6 * 4 * 32 + 32 * 64) + 64 * 64 + 32 * 64)            # MFMA issue cycles, DESIGN 9a
+          cycles = rows / 32 * 32 * (P * (6 * 4 + 24) + 48 + 24)     # MFMA issue cycles (i8 conv digits + bf16 piece products), DESIGN 9a
           cus = torch.cuda.get_device_properties(local).multi_processor_count
           bound_us = cycles / (4 * cus) / 2400.0
           policy = {"what": f"{k + 1} conventions in {2 * k + 1} pairing segments of {threads} kitchens: every actor, both sides, in one "

@@ -12,13 +12,18 @@
 //               base-128 fixed-point digits per output channel (policy_pack.h).  Integer accumulation is exact;
 //               with 4 digits the weight quantisation (2^-28 of the channel's largest weight) is below the f32
 //               rounding of the reference's own accumulation.
-//   fc1/fc2/head : v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-for-bit an fmaf chain.
+//   fc1/fc2/head : v_mfma_f32_32x32x16_bf16 on exact three-way bf16 splits of both operands (six piece products per
+//               f32 product, f32 accumulate; policy_pack.h): what is dropped is below 2^-23 of each product, and a
+//               32x32x16 tile costs 6 x 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64.  The weights are split at
+//               pack time, the activations in the kernel (two AND, two exact subtractions, three byte permutes per
+//               register pair).
 // Everything is evaluated transposed (feature index on the accumulator registers, row on the lanes): the output
 // of one layer is then directly the B operand of the next, with no lane movement and no LDS round trip.
 //
-// Bound: MFMA issue.  Cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 32*64) + 64*64 + 32*64;
-// cramped_room (P = 6, 4 digits) 23 040 cycles (PMC: SQ_VALU_MFMA_BUSY_CYCLES equals this model exactly).  Bytes: rows
-// are read once (W*H*20 B each).
+// Bound: MFMA issue + the VALU work between the layers (tools/probes/coexec.hip: they do not overlap on one SIMD).
+// MFMA cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 24*32) + 48*32 + 24*32; cramped_room
+// (P = 6, 4 digits) 11 520 cycles (23 040 with f32 MFMAs for the dense layers, as in round 1).  Bytes: rows are read
+// once (W*H*20 B each).
 //
 // Shape of the kernel (DESIGN.md 9a has the measurements behind each choice):
 //   * a workgroup = up to 8 wavefronts (two per SIMD; the kernel is held to 256 VGPRs and built with
@@ -37,6 +42,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "overcooked_hip.h"
@@ -50,6 +56,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 constexpr int kMaxOut = 8;
@@ -139,6 +147,41 @@ __device__ __forceinline__ void read_bfrags(const uint8_t *rowp, int pos_off, in
         }
 }
 
+// One dense-layer tile step: D += A (weight pieces, 8 bf16 per lane) x B (activation pieces, 8 bf16 per lane)
+__device__ __forceinline__ v16f mfma_bf16(const v4i a, const v4i b, const v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+// The six piece products kept of (w0 + w1 + w2) * (x0 + x1 + x2): weight piece, activation piece
+__device__ constexpr int kTermW[6] = {0, 0, 1, 0, 1, 2};
+__device__ constexpr int kTermX[6] = {0, 1, 0, 2, 1, 0};
+
+// max(x, 0) of an MFMA result in ONE instruction (fmaxf first quiets a possible signalling NaN with a second v_max)
+__device__ __forceinline__ float relu(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// Two f32 activations -> one packed dword per bf16 piece, x = hi + mid + lo exactly: the top 16 bits of an f32 are a
+// bf16 (truncation), what is left after subtracting it has at most 16 significant bits, and so on.
+__device__ __forceinline__ void split_pair(float x0, float x1, int &hi, int &mid, int &lo) {
+    const v2f xv = {x0, x1};
+    const v2f hv = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
+    const v2f rv = xv - hv;
+    const v2f mv = {__uint_as_float(__float_as_uint(rv.x) & 0xffff0000u), __uint_as_float(__float_as_uint(rv.y) & 0xffff0000u)};
+    const v2f qv = rv - mv;
+    hi = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u));
+    mid = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(rv.y), __float_as_uint(rv.x), 0x07060302u));
+    lo = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(qv.y), __float_as_uint(qv.x), 0x07060302u));
+}
+
+// fragment f (0..11) of position p of the fc1 section: voffset = lane * 16 (+ immediate), soffset scalar
+__device__ __forceinline__ v4i w1_from_l2(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane16, int p, int f) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(lane16) + (f & 3) * 1024,
+                                                         p * OC_POLICY_FC1_POS_BYTES + (f >> 2) * 4096, 0);
+    return __builtin_bit_cast(v4i, v);
+}
+
 // ---- work distribution, shared by the kernels below.  The tile table lists (row range, network, flags); its 32-row
 // blocks, in table order, are split EVENLY over the workgroups of the launch (one per CU), so a workgroup owns a contiguous
 // stretch of blocks [wg0, wg1) that may run through several tiles (weights are reloaded only when the network changes along
@@ -223,15 +266,22 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // conv weight digits: [kx*2+s][digit] x 16 bytes per lane, read from LDS per use or (when the LDS is needed for
     // large rows) held in registers; conv scale / bias per accumulator register likewise
     v4i wA[CONV_LDS ? 1 : 6][NDIG];
-    float csc[CONV_LDS ? 1 : 16], cbi[CONV_LDS ? 1 : 16];
+    // conv bias in units of the channel's fixed-point scale (policy_pack.h): the lowest digit's accumulator starts from it
+    v16i cbeta;
     const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
-    const float *sbl = reinterpret_cast<const float *>(lds + (a.L.off_conv_sb - a.L.off_conv)) + h * 16;
-    const v4f *w1g = nullptr;
-    const v4f *w1l = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc1 - wstart)) + lane;
+    const v16i *cbeta_lds = reinterpret_cast<const v16i *>(lds + (a.L.off_conv_sb - a.L.off_conv) + 128 + h * 64);
+    // dense-layer weight fragments: 16 bytes (8 bf16) per lane and MFMA, fragment f of a section at [f * 64 + lane]
+    // fc1 section of the network in global memory, as a buffer resource: scalar descriptor + scalar position offset + one
+    // 32-bit lane offset per load (as plain pointers hipcc keeps twelve 64-bit vector addresses alive through the loop)
+    __amdgpu_buffer_rsrc_t w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.packed), 0, 0, 0x00020000);
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+    const v4i *w1l = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_fc1 - wstart)) + lane;
     const float *b1 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b1 - wstart)) + h * 16;
-    const v4f *w2 = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
+    const v4i *w2 = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
     const float *b2 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b2 - wstart)) + h * 16;
-    const v4f *wh = reinterpret_cast<const v4f *>(lds_tail + (a.L.off_head - wstart)) + lane;
+    // head: only the outputs a < 8 are stored, [piece][k-group][8 h + a]; the other rows of the A operand are zero registers
+    const bool head_lane = col < 8;
+    const v4i *wh = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_head - wstart)) + (8 * h + (col & 7));
     const float *bh = reinterpret_cast<const float *>(lds_tail + (a.L.off_bh - wstart)) + h * 4;
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     const int colstep = H * OC_POLICY_C;
@@ -239,8 +289,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     bool trace_done = false, trace2_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
-    // conv result -> fc1 operand: f32(sum of digit accumulators) * scale + bias, ReLU; one accumulator register
-    // Digit pairs are pre-combined in integer arithmetic (acc_d * 128 + acc_{d+1}: exact, |.| < 2^26), so four digits cost
+    // conv result -> fc1 operand: relu(f32(sum of digit accumulators)), one accumulator register.  The channel's bias is
+    // already in the sum (the lowest digit's accumulator starts from it) and its scale is folded into the fc1 weights.
+    // Digit pairs are pre-combined in integer arithmetic (acc_d * 128 + acc_{d+1}: exact, |.| < 2^31), so four digits cost
     // 2 shift-adds + 2 conversions + 1 fma instead of 4 conversions + 3 fma: a wave's VALU work is not hidden under its MFMAs.
     auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
         float t;
@@ -250,13 +301,14 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             if (NDIG == 3) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[2][r]));
             if (NDIG == 4) t = __builtin_fmaf(t, 16384.0f, static_cast<float>(acc[2][r] * 128 + acc[3][r]));
         }
-        return CONV_LDS ? fmaxf(__builtin_fmaf(t, sbl[r], sbl[32 + r]), 0.f) : fmaxf(__builtin_fmaf(t, csc[CONV_LDS ? 0 : r], cbi[CONV_LDS ? 0 : r]), 0.f);
+        return fmaxf(t, 0.f);
     };
     auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
 #pragma unroll
-        for (int d = 0; d < NDIG; ++d)
+        for (int d = 0; d + 1 < NDIG; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[d][r] = 0;
+        acc[NDIG - 1] = CONV_LDS ? *cbeta_lds : cbeta;
         if (CONV_LDS) {
             // weight digits stream through a three-deep register ring, two kernel-column steps ahead of their
             // MFMAs; the group barriers pin that order (left alone, hipcc issues each read right before its
@@ -331,11 +383,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             for (int ks = 0; ks < (CONV_LDS ? 1 : 6); ++ks)
 #pragma unroll
                 for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
-            const float *sb = reinterpret_cast<const float *>(blob + a.L.off_conv_sb);
-#pragma unroll
-            for (int r = 0; r < (CONV_LDS ? 1 : 16); ++r) { csc[r] = sb[h * 16 + r]; cbi[r] = sb[32 + h * 16 + r]; }
+            cbeta = *reinterpret_cast<const v16i *>(blob + a.L.off_conv_sb + 128 + h * 64);
         }
-        w1g = reinterpret_cast<const v4f *>(blob + a.L.off_fc1) + lane;
+        w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(blob + a.L.off_fc1), 0, P * OC_POLICY_FC1_POS_BYTES, 0x00020000);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's share of the weight copy has landed
         __syncthreads();                                              // the network is in LDS
         loaded_net = net;
@@ -388,37 +438,78 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 for (int r = 0; r < 16; ++r) h1[m][r] = bq[m * 8 + (r >> 2)][r & 3];
         }
         if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
-        v16f x;
+        // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
+        auto make_operand = [&](v4i (&dst)[3][2], int j) {            // pair j = accumulator registers 2j, 2j + 1
+            int hi, mid, lo;
+            split_pair(combine(acc, 2 * j), combine(acc, 2 * j + 1), hi, mid, lo);
+            dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = mid; dst[2][j >> 2][j & 3] = lo;
+        };
+        v4i xb[3][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = combine(acc, r);
+        for (int j = 0; j < 8; ++j) make_operand(xb, j);
         if (traced2) stamp(a, wave, lane, 19);
 
-        for (int p = 0; p < P; ++p) {
-            v4f w1r[8];                                               // fc1 operands of this position
+        // fc1 fragments of a position [piece][k-group][out half].  They are requested one position ahead, into the registers
+        // the MFMAs of the current position have just read, so an L2 round trip (fc1 not LDS-resident) has the operand
+        // conversion and the next conv to land in.
+        v4i w1r[3][2][2];
+        auto load_w1 = [&](int p) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) w1r[q] = FC1_LDS ? w1l[(p * 8 + q) * 64] : w1g[(p * 8 + q) * 64];
-            __builtin_amdgcn_sched_barrier(0);                        // keep the issue up here (hipcc sinks it to the use)
-            if (p + 1 < P) conv(acc, bfr);                            // conv of position p+1
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
-            read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
-            __builtin_amdgcn_sched_barrier(0);
-            // fc1 partial: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row], step f = 2s + m
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx) {
-                h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx) & 3], x[sidx], h1[0], 0, 0, 0);
-                h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[sidx >> 1][(2 * sidx + 1) & 3], x[sidx], h1[1], 0, 0, 0);
-                x[sidx] = combine(acc, sidx);                         // next position's operand, once this one is consumed
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo)
+                        w1r[q][g][mo] = FC1_LDS ? w1l[(p * 12 + (q * 2 + g) * 2 + mo) * 64]
+                                                : w1_from_l2(w1g, lane16, p, (q * 2 + g) * 2 + mo);
+        };
+        load_w1(0);
+        // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x six piece products x two
+        // output halves.  Unless it is the last, the next position's operand is built around them: the second k-group's
+        // registers (pairs 4..7) into spare registers next to the first group's MFMAs, the first group's (pairs 0..3) in place
+        // once its MFMAs have issued.
+        auto position = [&](int p, auto last_tag) {
+            constexpr bool kLast = decltype(last_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!kLast) conv(acc, bfr);                               // conv of position p+1
+            __builtin_amdgcn_sched_barrier(0);
+            if (!kLast) {
+                advance();
+                read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v4i nb1[3];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                h1[0] = mfma_bf16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
+                h1[1] = mfma_bf16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
+                if (!kLast && t < 4) {
+                    int hi, mid, lo;
+                    split_pair(combine(acc, 8 + 2 * t), combine(acc, 9 + 2 * t), hi, mid, lo);
+                    nb1[0][t] = hi; nb1[1][t] = mid; nb1[2][t] = lo;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                h1[0] = mfma_bf16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
+                h1[1] = mfma_bf16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
+            }
+            if (!kLast) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_w1(p + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) make_operand(xb, t);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xb[q][1] = nb1[q];
             }
             if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
-        }
+        };
+        for (int p = 0; p + 1 < P; ++p) position(p, std::false_type());
+        position(P - 1, std::true_type());
         if (traced) stamp(a, wave, lane, 4);
         if (traced2) stamp(a, wave, lane, 26);
-        // dense-layer operands: all issued here, consumed below
-        v4f w2r[2][8], whr[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { w2r[0][q] = w2[q * 64]; w2r[1][q] = w2[(8 + q) * 64]; }
-        v16f h2[2], out;
+        v16f h2[2], out, out2;
         {
             const v4f *bq = reinterpret_cast<const v4f *>(b2);
 #pragma unroll
@@ -427,7 +518,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 for (int r = 0; r < 16; ++r) h2[m][r] = bq[m * 8 + (r >> 2)][r & 3];
             const v4f bhv = *reinterpret_cast<const v4f *>(bh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[r] = r < 4 ? bhv[r] : 0.f;
+            for (int r = 0; r < 16; ++r) { out[r] = r < 4 ? bhv[r] : 0.f; out2[r] = 0.f; }
         }
         // the staging area is free: start the copy of this wavefront's next block under the dense layers
         wave_lds_sync();
@@ -436,35 +527,62 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 27);
 
-        // ---- fc2: h2^T[n2][row] = relu(b2 + W2 relu(h1)), input half m, step f = 2s + m2 ----
+        // ---- fc2: h2^T[n2][row] = b2 + W2 relu(h1): four k-groups (input half kg >> 1, registers 8 (kg & 1) ..) ----
+        // the operand pieces of k-group kg + 1 are built under the MFMAs of k-group kg
+        auto split_group = [&](const v16f &v, int g, v4i (&dst)[3]) {  // relu + split of registers 8g .. 8g + 7
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[0][r] = fmaxf(h1[0][r], 0.f);
+            for (int j = 0; j < 4; ++j) {
+                int hi, mid, lo;
+                split_pair(relu(v[8 * g + 2 * j]), relu(v[8 * g + 2 * j + 1]), hi, mid, lo);
+                dst[0][j] = hi; dst[1][j] = mid; dst[2][j] = lo;
+            }
+        };
+        {
+            v4i hb[2][3];                                             // [parity of kg][piece]
+            v4i w2r[2][3][2];                                         // [parity of kg][piece][out half]
+            auto load_w2 = [&](int kg) {
 #pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx) & 3], h1[0][sidx], h2[0], 0, 0, 0);
-            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[0][sidx >> 1][(2 * sidx + 1) & 3], h1[0][sidx], h2[1], 0, 0, 0);
-            h1[1][sidx] = fmaxf(h1[1][sidx], 0.f);                    // in the shadow: needed by the second half
-        }
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) whr[q] = wh[q * 64];             // head operands: in flight under the second half
+                    for (int mo = 0; mo < 2; ++mo) w2r[kg & 1][q][mo] = w2[((q * 4 + kg) * 2 + mo) * 64];
+            };
+            load_w2(0);
+            split_group(h1[0], 0, hb[0]);
 #pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx) & 3], h1[1][sidx], h2[0], 0, 0, 0);
-            h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[1][sidx >> 1][(2 * sidx + 1) & 3], h1[1][sidx], h2[1], 0, 0, 0);
+            for (int kg = 0; kg < 4; ++kg) {
+                if (kg + 1 < 4) load_w2(kg + 1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    h2[0] = mfma_bf16(w2r[kg & 1][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
+                    h2[1] = mfma_bf16(w2r[kg & 1][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
+                }
+                if (kg + 1 < 4) split_group(h1[(kg + 1) >> 1], (kg + 1) & 1, hb[(kg + 1) & 1]);
+            }
         }
         if (traced) stamp(a, wave, lane, 5);
         if (traced2) stamp(a, wave, lane, 28);
-        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; step f = 16m + s ----
+        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; two accumulators so consecutive MFMAs do not wait for each other ----
+        {
+            v4i gb[2][3], whr[2][3];
+            auto load_wh = [&](int kg) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2[0][r] = fmaxf(h2[0][r], 0.f);
+                for (int q = 0; q < 3; ++q) whr[kg & 1][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
+            };
+            load_wh(0);
+            split_group(h2[0], 0, gb[0]);
 #pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[sidx >> 2][sidx & 3], h2[0][sidx], out, 0, 0, 0);
-            h2[1][sidx] = fmaxf(h2[1][sidx], 0.f);
+            for (int kg = 0; kg < 4; ++kg) {
+                if (kg + 1 < 4) load_wh(kg + 1);
+#pragma unroll
+                for (int t = 0; t < 6; t += 2) {
+                    out = mfma_bf16(whr[kg & 1][kTermW[t]], gb[kg & 1][kTermX[t]], out);
+                    out2 = mfma_bf16(whr[kg & 1][kTermW[t + 1]], gb[kg & 1][kTermX[t + 1]], out2);
+                }
+                if (kg + 1 < 4) split_group(h2[(kg + 1) >> 1], (kg + 1) & 1, gb[(kg + 1) & 1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] += out2[r];
         }
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx)
-            out = __builtin_amdgcn_mfma_f32_32x32x2f32(whr[4 + (sidx >> 2)][sidx & 3], h2[1][sidx], out, 0, 0, 0);
         if (traced) stamp(a, wave, lane, 6);
         if (traced2) stamp(a, wave, lane, 29);
 
@@ -681,20 +799,23 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     a.trace = g_trace;
     a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
-    // CU; otherwise fc1 (8 KB per conv position) stays in L2 and is prefetched into registers per position.
+    // CU; otherwise fc1 (12 KB per conv position) stays in L2 and is prefetched into registers per position.
     constexpr long long kLds = 160 * 1024;
     const long long w_tail_all = a.L.off_bh + 32 - a.L.off_fc1, w_tail_small = a.L.off_bh + 32 - a.L.off_b1;
     const long long w_conv = a.L.off_fc1 - a.L.off_conv, obs1 = a.lds_wave_bytes;
-    // Plan, in order of preference (the kernel fits 256 registers, so two wavefronts per SIMD can hide each
-    // other's LDS / VALU phases behind MFMAs):
-    //   8 wavefronts, conv digits + small tail resident, fc1 (8 KB per position) prefetched from L2 per position;
-    //   4 wavefronts with everything resident; 4 with fc1 from L2; then fewer wavefronts for very large rows.
+    // Plan (profiles/r02_policy_plan_sweep.log):
+    //   8 wavefronts (two per SIMD, 256 registers each) when eight staging areas fit next to the conv digits and the small
+    //   tail: fc1 (12 KB per position) is then prefetched from L2 one position ahead (cramped_room: 102 us for 245 760
+    //   evaluations against 105-107 with four wavefronts);
+    //   otherwise 4 wavefronts (one per SIMD, 512 registers) with the conv digits in REGISTERS -- at one wavefront per SIMD the
+    //   24 LDS fragment reads per position are latency nobody hides (counter_circuit 133 vs 147 us, forced_coordination 134
+    //   vs 156) -- and fc1 LDS-resident if that fits, else from L2; then fewer wavefronts for very large rows.
     int waves = 8;
     bool fc1_lds = false, conv_lds = true;
     if (w_conv + w_tail_small + 8 * obs1 > kLds) {
         waves = 4;
-        if (w_conv + w_tail_all + 4 * obs1 <= kLds) fc1_lds = true;
-        else if (w_conv + w_tail_small + 4 * obs1 > kLds) conv_lds = false;
+        conv_lds = false;
+        fc1_lds = w_tail_all + 4 * obs1 <= kLds;
     }
     // Two cooperative plans for the grids where eight staging areas do not fit were built and measured in round 2 -- two
     // wavefronts of a SIMD sharing one staged block and splitting its conv positions, and a conv-wavefront / dense-wavefront

@@ -12,9 +12,18 @@
 //
 // Lane maps used (cdna_hip_programming.md section 3):
 //   C/D of every 32x32 MFMA:  column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), reg 0..15
-//   A of v_mfma_f32_32x32x2_f32: lane l holds A[row l & 31][k = l >> 5]
-//   A/B of v_mfma_i32_32x32x32_i8: lane l holds 16 bytes; the pairing of A byte j / lane half h with B byte j /
-//     lane half h is all the packing relies on (integer sums do not care about the order of k).
+//   A/B of v_mfma_f32_32x32x16_bf16: lane l holds 8 bf16 (16 bytes): A[row l & 31][k = 8 * (l >> 5) + i], B likewise by column
+//   A/B of v_mfma_i32_32x32x32_i8: lane l holds 16 bytes
+//   for both, the pairing of A element i / lane half h with B element i / lane half h is all the packing relies on
+//   (which k a slot stands for is free, as long as A and B agree).
+//
+// Dense layers (fc1, fc2, head): f32 x f32 products on the bf16 matrix pipe.  Every f32 value is the exact sum of three
+// bf16 pieces (8 significant bits each); the weights are split here, once (round to nearest), the activations in the kernel
+// (by truncation: two AND and two exact subtractions).  w * x is then evaluated as the six piece products of weight
+// piece a and activation piece b with a + b <= 2, accumulated in f32: what is dropped is below 2^-23 of |w * x| -- under
+// the rounding of an f32 accumulation -- at 6 x 32 cycles per 32x32x16 tile where v_mfma_f32_32x32x2_f32 needs 8 x 64.
+// An activation register r of lane half h (D layout of the previous layer) goes to B slot i = r & 7 of k-group r >> 3;
+// the weight fragments below are stored to match, so a layer's result feeds the next with no lane movement.
 #ifndef OC_POLICY_PACK_H
 #define OC_POLICY_PACK_H
 
@@ -26,12 +35,13 @@
 #define OC_HD
 #endif
 
-#define OC_POLICY_MAGIC 0x31504F43          /* "COP1" */
+#define OC_POLICY_MAGIC 0x32504F43          /* "COP2" */
 #define OC_POLICY_C 20
 #define OC_POLICY_O 32                      /* conv channels = hidden / 2 */
 #define OC_POLICY_HID 64
 #define OC_POLICY_SLAB 64                   /* k per kernel column kx: 3 tiles x 20 channels = 60, padded */
 #define OC_POLICY_HEADER_BYTES 64
+#define OC_POLICY_FC1_POS_BYTES (3 * 2 * 2 * 64 * 16)   /* fc1 fragments of one conv position */
 
 // Byte offsets of the sections of one packed network (all multiples of 16).
 struct oc_policy_layout {
@@ -45,13 +55,13 @@ OC_HD inline oc_policy_layout oc_policy_make_layout(int W, int H, int digits, in
     L.W = W; L.H = H; L.PH = H - 2; L.P = (W - 2) * (H - 2); L.digits = digits; L.n_out = n_out;
     int64_t o = OC_POLICY_HEADER_BYTES;
     L.off_conv = o;    o += (int64_t)6 * digits * 64 * 16;         // [kx*2+s][digit][lane][16] int8
-    L.off_conv_sb = o; o += 2 * 2 * 16 * 4;                        // scale[h][reg], bias[h][reg] f32
-    L.off_fc1 = o;     o += (int64_t)L.P * 8 * 64 * 4 * 4;         // [p][q][lane][4] f32, step f = 4q+j = 2s+m
-    L.off_b1 = o;      o += 2 * 2 * 16 * 4;                        // [m][h][reg]
-    L.off_fc2 = o;     o += 2 * 8 * 64 * 4 * 4;                    // [m][q][lane][4], f = 2s+m2
+    L.off_conv_sb = o; o += 2 * 2 * 16 * 4;                        // scale[h][reg] f32 (folded into fc1; kept for inspection), bias[h][reg] int32 in units of the scale
+    L.off_fc1 = o;     o += (int64_t)L.P * OC_POLICY_FC1_POS_BYTES; // [p][piece][k-group 2][out half 2][lane][8] bf16
+    L.off_b1 = o;      o += 2 * 2 * 16 * 4;                        // [m][h][reg] f32
+    L.off_fc2 = o;     o += 3 * 4 * 2 * 64 * 16;                   // [piece][k-group 4][out half 2][lane][8] bf16
     L.off_b2 = o;      o += 2 * 2 * 16 * 4;
-    L.off_head = o;    o += 8 * 64 * 4 * 4;                        // [q][lane][4], f = 16m+s
-    L.off_bh = o;      o += 2 * 4 * 4;                             // [h][reg 0..3]
+    L.off_head = o;    o += 3 * 4 * 16 * 16;                       // [piece][k-group 4][slot = 8h + a][8] bf16, outputs a < 8 only
+    L.off_bh = o;      o += 2 * 4 * 4;                             // [h][reg 0..3] f32
     L.total = (o + 255) / 256 * 256;
     return L;
 }
@@ -88,13 +98,39 @@ OC_HD inline long long oc_policy_qmax(int digits) {
     return q;
 }
 
-// Fixed-point conv weight: w ~ (absmax / qmax) * sum_d digit_d * 128^(digits-1-d), digit 0 the top digit in
-// [-127, 127], the others balanced in [-64, 63].  With 4 digits the quantisation step is absmax * 2^-28: below
-// the f32 rounding of the reference's own accumulation.
-OC_HD inline int oc_policy_conv_digit(float w, float absmax, int digits, int d) {
-    if (!(absmax > 0.f) || !(w == w)) return 0;
+// Fixed-point scale of conv output channel o: one unit of the lowest weight digit.  absmax / qmax uses every bit of the
+// digits; a bias that large next to the weights that it would not fit the 32-bit accumulator in these units (|b| > ~4 absmax)
+// coarsens the unit instead -- the channel's value is then dominated by the bias, and the relative error stays 2^-24 class.
+OC_HD inline float oc_policy_conv_scale(const oc_policy_weights &w, int o, int digits) {
+    const float m = oc_policy_conv_absmax(w.conv_w, o);
+    float b = w.conv_b[o];
+    b = b < 0.f ? -b : b;
+    if (!(b == b) || b > 3.0e38f) b = 0.f;                              // NaN / inf bias: the channel is garbage either way
+    double s = (double)m / (double)oc_policy_qmax(digits);
+    const double sb = (double)b / 1073741824.0;                         // |bias| <= 2^30 units
+    if (sb > s) s = sb;
+    const float f = (float)s;
+    return f > 0.f ? f : 1.0f;                                          // all-zero channel: any unit does
+}
+// bias of channel o in units of its scale: the initial value of the lowest digit's accumulator
+OC_HD inline int32_t oc_policy_conv_bias_units(const oc_policy_weights &w, int o, int digits) {
+    const float b = w.conv_b[o];
+    if (!(b == b)) return 0;
+    double x = (double)b / (double)oc_policy_conv_scale(w, o, digits);
+    if (x > 1073741824.0) x = 1073741824.0;
+    if (x < -1073741824.0) x = -1073741824.0;
+    return (int32_t)(x < 0 ? x - 0.5 : x + 0.5);
+}
+
+// Fixed-point conv weight: w ~ scale * sum_d digit_d * 128^(digits-1-d), digit 0 the top digit in [-127, 127], the others
+// balanced in [-64, 63].  With 4 digits and scale = absmax / qmax the quantisation step is absmax * 2^-28: below the f32
+// rounding of the reference's own accumulation.
+OC_HD inline int oc_policy_conv_digit(float w, float scale, int digits, int d) {
+    if (!(scale > 0.f) || !(w == w)) return 0;
     const long long qmax = oc_policy_qmax(digits);
-    double x = (double)w / (double)absmax * (double)qmax;
+    double x = (double)w / (double)scale;
+    if (x > (double)qmax) x = (double)qmax;
+    if (x < -(double)qmax) x = -(double)qmax;
     long long q = (long long)(x < 0 ? x - 0.5 : x + 0.5);
     if (q > qmax) q = qmax;
     if (q < -qmax) q = -qmax;
@@ -117,41 +153,64 @@ OC_HD inline int8_t oc_policy_pack_conv(const oc_policy_layout &L, const oc_poli
     if (kl >= 60) return 0;
     const int ky = kl / OC_POLICY_C, c = kl % OC_POLICY_C;
     const float v = w.conv_w[((o * OC_POLICY_C + c) * 3 + kx) * 3 + ky];
-    return (int8_t)oc_policy_conv_digit(v, oc_policy_conv_absmax(w.conv_w, o), L.digits, d);
+    return (int8_t)oc_policy_conv_digit(v, oc_policy_conv_scale(w, o, L.digits), L.digits, d);
 }
-// conv scale / bias, idx over [2 kinds][2 h][16 reg]
-OC_HD inline float oc_policy_pack_conv_sb(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
+// conv scale (f32) / bias in scale units (int32), idx over [2 kinds][2 h][16 reg], as 32-bit words
+OC_HD inline uint32_t oc_policy_pack_conv_sb(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
     const int reg = (int)(idx & 15), h = (int)((idx >> 4) & 1), kind = (int)(idx >> 5);
     const int o = oc_mfma_row(reg, h);
-    if (kind) return w.conv_b[o];
-    const float m = oc_policy_conv_absmax(w.conv_w, o);
-    return (float)((double)m / (double)oc_policy_qmax(L.digits));
+    union { float f; uint32_t u; } cv;
+    if (kind) return (uint32_t)oc_policy_conv_bias_units(w, o, L.digits);
+    cv.f = oc_policy_conv_scale(w, o, L.digits);
+    return cv.u;
 }
-// The dense layers' A operands are stored so that one lane reads four consecutive MFMA steps with one 16-byte
-// load: [.. ][q = f / 4][lane][f % 4], f the position of the MFMA in the kernel's issue order.
-// fc1, idx over [P][8 q][64 lane][4]: issue order f = 2 s + m (k-step s = 0..15, output half m)
-OC_HD inline float oc_policy_pack_fc1(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
-    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63), p = (int)(idx >> 11);
-    const int s = f >> 1, m = f & 1;
-    const int n = 32 * m + (lane & 31), o = oc_mfma_row(s, lane >> 5);
-    return w.fc1_w[(int64_t)n * (OC_POLICY_O * L.P) + o * L.P + p];
+// ---- bf16 pieces of an f32 weight: w = piece0 + piece1 + piece2 exactly (each rounded to nearest even of what is left)
+OC_HD inline uint32_t oc_f32_bits(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+OC_HD inline float oc_bits_f32(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+OC_HD inline uint16_t oc_bf16_rne(float f) {
+    const uint32_t u = oc_f32_bits(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));   // inf / NaN keep their class
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+OC_HD inline uint16_t oc_policy_bf16_piece(float w, int piece) {
+    uint16_t b = oc_bf16_rne(w);
+    for (int i = 0; i < piece; ++i) {
+        w = w - oc_bits_f32((uint32_t)b << 16);                      // exact: the remainder has at most 16, then 8 significant bits
+        b = oc_bf16_rne(w);
+    }
+    return b;
+}
+// activation register (k-group g, slot i, lane half h) -> feature index inside a 32-wide half
+OC_HD inline int oc_policy_kslot_row(int g, int i, int h) { return oc_mfma_row(8 * g + i, h); }
+
+// The dense layers' A operands: one 16-byte fragment per lane and MFMA, 8 bf16 = k slots i = 0..7 of the lane's half.
+// fc1, idx (in bf16 elements) over [P][3 piece][2 g][2 mo][64 lane][8 i]: out n = 32 mo + (lane & 31), in channel o = row(g, i, h)
+OC_HD inline uint16_t oc_policy_pack_fc1(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63), mo = (int)((idx >> 9) & 1), g = (int)((idx >> 10) & 1);
+    const int piece = (int)((idx >> 11) % 3), p = (int)((idx >> 11) / 3);
+    const int n = 32 * mo + (lane & 31), o = oc_policy_kslot_row(g, i, lane >> 5);
+    // the conv channel's fixed-point unit is folded in here: the kernel feeds relu(integer conv sum + bias units) as is
+    return oc_policy_bf16_piece(w.fc1_w[(int64_t)n * (OC_POLICY_O * L.P) + o * L.P + p] * oc_policy_conv_scale(w, o, L.digits), piece);
 }
 // hidden-layer biases, idx over [2 m][2 h][16 reg]
 OC_HD inline float oc_policy_pack_hbias(const float *b, int64_t idx) {
     const int reg = (int)(idx & 15), h = (int)((idx >> 4) & 1), m = (int)(idx >> 5);
     return b[32 * m + oc_mfma_row(reg, h)];
 }
-// fc2, idx over [2 m][8 q][64 lane][4]: input half m, issue order inside it f = 2 s + m2
-OC_HD inline float oc_policy_pack_fc2(const oc_policy_weights &w, int64_t idx) {
-    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63), m = (int)(idx >> 11);
-    const int s = f >> 1, m2 = f & 1;
-    return w.fc2_w[(32 * m2 + (lane & 31)) * OC_POLICY_HID + 32 * m + oc_mfma_row(s, lane >> 5)];
+// fc2, idx over [3 piece][4 kg][2 mo][64 lane][8 i]: k-group kg = 2 mi + g covers input half mi, registers 8g..8g+7
+OC_HD inline uint16_t oc_policy_pack_fc2(const oc_policy_weights &w, int64_t idx) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63), mo = (int)((idx >> 9) & 1), kg = (int)((idx >> 10) & 3);
+    const int piece = (int)(idx >> 12);
+    const int in = 32 * (kg >> 1) + oc_policy_kslot_row(kg & 1, i, lane >> 5);
+    return oc_policy_bf16_piece(w.fc2_w[(32 * mo + (lane & 31)) * OC_POLICY_HID + in], piece);
 }
-// head, idx over [8 q][64 lane][4]: issue order f = 16 m + s; rows >= n_out are zero
-OC_HD inline float oc_policy_pack_head(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
-    const int f = (int)(4 * ((idx >> 8) & 7) + (idx & 3)), lane = (int)((idx >> 2) & 63);
-    const int m = f >> 4, s = f & 15, a = lane & 31;
-    return a < L.n_out ? w.head_w[a * OC_POLICY_HID + 32 * m + oc_mfma_row(s, lane >> 5)] : 0.f;
+// head, idx over [3 piece][4 kg][16 slot = 8 h + a][8 i]: outputs a < 8 (rows 8..31 of the MFMA's A operand are zero
+// registers in the kernel, not stored)
+OC_HD inline uint16_t oc_policy_pack_head(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
+    const int i = (int)(idx & 7), a = (int)((idx >> 3) & 7), h = (int)((idx >> 6) & 1), kg = (int)((idx >> 7) & 3);
+    const int piece = (int)(idx >> 9);
+    const int in = 32 * (kg >> 1) + oc_policy_kslot_row(kg & 1, i, h);
+    return a < L.n_out ? oc_policy_bf16_piece(w.head_w[a * OC_POLICY_HID + in], piece) : (uint16_t)0;
 }
 // head bias, idx over [2 h][4 reg]: output a = reg + 4 h
 OC_HD inline float oc_policy_pack_bh(const oc_policy_layout &L, const oc_policy_weights &w, int64_t idx) {
@@ -173,12 +232,12 @@ OC_HD inline uint32_t oc_policy_pack_word(const oc_policy_layout &L, const oc_po
             v |= (uint32_t)(uint8_t)oc_policy_pack_conv(L, w, b - L.off_conv + i) << (8 * i);
         return v;
     }
-    if (b < L.off_fc1) cv.f = oc_policy_pack_conv_sb(L, w, (b - L.off_conv_sb) / 4);
-    else if (b < L.off_b1) cv.f = oc_policy_pack_fc1(L, w, (b - L.off_fc1) / 4);
+    if (b < L.off_fc1) return oc_policy_pack_conv_sb(L, w, (b - L.off_conv_sb) / 4);
+    else if (b < L.off_b1) { const int64_t e = (b - L.off_fc1) / 2; return oc_policy_pack_fc1(L, w, e) | ((uint32_t)oc_policy_pack_fc1(L, w, e + 1) << 16); }
     else if (b < L.off_fc2) cv.f = oc_policy_pack_hbias(w.fc1_b, (b - L.off_b1) / 4);
-    else if (b < L.off_b2) cv.f = oc_policy_pack_fc2(w, (b - L.off_fc2) / 4);
+    else if (b < L.off_b2) { const int64_t e = (b - L.off_fc2) / 2; return oc_policy_pack_fc2(w, e) | ((uint32_t)oc_policy_pack_fc2(w, e + 1) << 16); }
     else if (b < L.off_head) cv.f = oc_policy_pack_hbias(w.fc2_b, (b - L.off_b2) / 4);
-    else if (b < L.off_bh) cv.f = oc_policy_pack_head(L, w, (b - L.off_head) / 4);
+    else if (b < L.off_bh) { const int64_t e = (b - L.off_head) / 2; return oc_policy_pack_head(L, w, e) | ((uint32_t)oc_policy_pack_head(L, w, e + 1) << 16); }
     else if (b < L.off_bh + 32) cv.f = oc_policy_pack_bh(L, w, (b - L.off_bh) / 4);
     else return 0u;
     return cv.u;

@@ -63,7 +63,7 @@ def run(layout, threads, k, digits=4, rows_per_tile=None, iters=50, with_torch=T
     P = (W - 2) * (H - 2)
     rows = 2 * 2 * n                                                                 # actor + critic evaluations
     flop = rows * 2 * (P * 180 * 32 + P * 32 * 64 + 64 * 64 + 64 * (6 + 1) / 2)
-    mfma_cycles = rows / 32 * (P * (6 * digits * 32 + 32 * 64) + 64 * 64 + 32 * 64)
+    mfma_cycles = rows / 32 * 32 * (P * (6 * digits + 24) + 48 + 24)      # i8 conv digits + bf16 piece products, 32 cycles each
     cu = torch.cuda.get_device_properties(0).multi_processor_count
     out = {"layout": layout, "kitchens": n, "segments": G, "conventions": k + 1, "digits": digits, "tiles": plan.n_tiles,
            "rows_per_tile": plan.rows_per_tile, "network_evaluations": rows, "fused_us": round(us, 1),

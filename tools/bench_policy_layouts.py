@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""[Historical: the plans this script compares (OC_POLICY_PLAN=pair / cf) were removed from the product after they measured slower;
-check out the commits named in DESIGN.md 9a to re-run it.  Logs: profiles/r02_policy_pair_split.log, r02_policy_conv_dense_split.log]
-
-Policy kernel on the grids whose staging areas limit LDS to four (asymmetric_advantages, counter_circuit, the 5x5
-layouts): the pair plan (two wavefronts per SIMD sharing one staged block, oc_policy_pair_kernel) against the
-one-wavefront-per-SIMD plan.  OC_POLICY_PLAN is read once per process: run once with OC_POLICY_PLAN=nopair, once without.
-Prints per layout the policy launch alone (actors + critics, both sides) and the whole step of config 4's per-GPU share."""
+"""Policy kernel (oc_policy_forward) on every classic layout: the launch alone (4 actors + 4 critics, both sides) and the
+whole policies-in-the-loop step of config 4's per-GPU share.  The bound printed is the MFMA issue time of the launch:
+per 32 rows P x (6 x digits + 24) + 48 + 24 matrix instructions of 32 cycles each on one SIMD (i8 conv digits + bf16
+piece products of the dense layers), at 2.4 GHz and at the ~2.1 GHz the chip holds under this load.
+Round-2 history: the same script compared the removed two-wavefront plans (profiles/r02_policy_pair_split.log,
+r02_policy_conv_dense_split.log; f32 dense layers then, 23 040 cycles per 32 rows on cramped_room against 11 520 now)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +13,7 @@ from diverse_conventions_amd import get_base_layout_params
 from diverse_conventions_amd.fused_policy import TILE_ACT, PackedNetworks, PolicyPlan
 
 plan = os.environ.get("OC_POLICY_PLAN", "default")
+DIGITS = 4
 for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("counter_circuit", 30720), ("forced_coordination", 61440), ("coordination_ring", 61440)):
     params = get_base_layout_params(layout, 200)
     W, H = params["width"], params["height"]
@@ -40,7 +40,7 @@ for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("c
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
     evals = 2 * rows
-    cycles = evals / 32 * (P * (6 * 4 * 32 + 32 * 64) + 64 * 64 + 32 * 64)
+    cycles = evals / 32 * 32 * (P * (6 * DIGITS + 24) + 48 + 24)
     bound24 = cycles / 1024 / 2400.0
     print(json.dumps({"plan": plan, "layout": layout, "evaluations": evals, "us": round(us, 1), "issue_bound_us_at_2.4GHz": round(bound24, 1),
                       "frac_of_bound_2.4GHz": round(bound24 / us, 3), "frac_at_2.1GHz": round(bound24 * 2.4 / 2.1 / us, 3)}), flush=True)
