@@ -109,13 +109,34 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void stage_rows(const PolicyArgs &a, uint8_t *ldsw, long long brow, int lane) {
     const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
     const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
-    if (base + 16ll * n16 <= obs_bytes) {                             // whole block inside the tensor (wave-uniform)
+    // Fast path: whole 1 KB instructions only.  The staging area is padded to a multiple of 1 KB (lds_wave_bytes), so the last
+    // instruction may run past the block's 32 rows into the following rows of the tensor (read, never used).  Eight
+    // instructions share one LDS base (M0), told apart by the signed 13-bit immediate offset that is added to both addresses:
+    // every change of M0 holds the wavefront ~0.12 us behind the copies in flight (one M0 per instruction measured 1.5 us for
+    // the 13 of a cramped_room block), and hipcc re-writes M0 in every basic block -- hence straight-line groups.
+    const int n_kb = (n16 + 63) >> 6;
+    if (base + 1024ll * n_kb <= obs_bytes) {                          // (wave-uniform)
         const int8_t *src = a.obs + base + 16 * lane;
+#define OC_DMA(J) __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, ((J) - 4) * 1024, 0);
         int it = 0;
-        for (; (it + 1) * 64 <= n16; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsw + it * 1024), 16, 0, 0);
-        if (it * 64 + lane < n16)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + it * 1024), (lptr_t)(ldsw + it * 1024), 16, 0, 0);
+        for (; it + 8 <= n_kb; it += 8) {
+            const int8_t *s4 = src + (it + 4) * 1024;
+            uint8_t *d4 = ldsw + (it + 4) * 1024;
+            OC_DMA(0) OC_DMA(1) OC_DMA(2) OC_DMA(3) OC_DMA(4) OC_DMA(5) OC_DMA(6) OC_DMA(7)
+        }
+        const int8_t *s4 = src + (it + 4) * 1024;
+        uint8_t *d4 = ldsw + (it + 4) * 1024;
+        switch (n_kb - it) {                                          // the remaining 0..7, one M0 for all of them
+        case 7: OC_DMA(0) OC_DMA(1) OC_DMA(2) OC_DMA(3) OC_DMA(4) OC_DMA(5) OC_DMA(6) break;
+        case 6: OC_DMA(0) OC_DMA(1) OC_DMA(2) OC_DMA(3) OC_DMA(4) OC_DMA(5) break;
+        case 5: OC_DMA(0) OC_DMA(1) OC_DMA(2) OC_DMA(3) OC_DMA(4) break;
+        case 4: OC_DMA(0) OC_DMA(1) OC_DMA(2) OC_DMA(3) break;
+        case 3: OC_DMA(0) OC_DMA(1) OC_DMA(2) break;
+        case 2: OC_DMA(0) OC_DMA(1) break;
+        case 1: OC_DMA(0) break;
+        default: break;
+        }
+#undef OC_DMA
         return;
     }
     for (int it = 0; it * 64 < n16; ++it) {
@@ -521,6 +542,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             for (int r = 0; r < 16; ++r) { out[r] = r < 4 ? bhv[r] : 0.f; out2[r] = 0.f; }
         }
         // the staging area is free: start the copy of this wavefront's next block under the dense layers
+        // (all at once: spreading the LDS-DMA instructions between the MFMA groups of fc2 / head was measured -- each still holds
+        // the wavefront for its ~0.1 us, the time just moves there: 99.4 vs 95.2 us per cramped_room launch)
         wave_lds_sync();
         if (blk + nwaves < last)
             stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
@@ -797,7 +820,7 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
     a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.row_select = d_row_select; a.sample = sample_mode;
     a.trace = g_trace;
-    a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 15) / 16 * 16;
+    a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 1023) / 1024 * 1024;      // whole 1 KB LDS-DMA instructions (stage_rows)
     // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
     // CU; otherwise fc1 (12 KB per conv position) stays in L2 and is prefetched into registers per position.
     constexpr long long kLds = 160 * 1024;

@@ -245,8 +245,10 @@ int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, vo
  * valid 20 -> hidden/2, ReLU, flatten, Linear -> hidden, ReLU, Linear -> hidden, ReLU) + one Linear head
  * (6 action logits, utils/act.py + distributions.py:60-80, or 1 value, `v_out`).  hidden_size 64 (train_xp.sh:12);
  * other sizes return OC_ERR_UNSUPPORTED.  Numerics: conv in exact integer arithmetic on `digits` base-128
- * fixed-point weight digits (4: quantisation 2^-28 of each channel's largest weight), dense layers on f32-input
- * MFMA (an fmaf chain); outputs agree with the reference's f32 forward to ~1e-6. */
+ * fixed-point weight digits (4: quantisation 2^-28 of each channel's largest weight; the channel's bias rides in the
+ * same units), dense layers as f32 x f32 products on the bf16 matrix pipe (both operands split exactly into three bf16
+ * pieces, six piece products each, f32 accumulate: what is dropped is below 2^-23 of a product); outputs agree with
+ * the reference's f32 forward to ~1e-6 of their magnitude (tools/policy_accuracy.py measures it against float64). */
 typedef struct {
     int32_t width, height;     /* observation grid; rows are width*height*20 int8, C fastest, W before H */
     int32_t hidden;            /* reference --hidden_size: 64 */

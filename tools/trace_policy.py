@@ -50,6 +50,9 @@ if len(fine):
     for nm, v in zip(names2, np.median(d2, axis=0)):
         print(f"    {nm:42s} {v:6.2f}")
     print(f"    {'whole block':42s} {np.median(fine[:, -1] - fine[:, 0]):6.2f}")
+    extra = buf[buf[:, 30] > 0][:, 31].astype(np.float64) / 100.0
+    if extra.any():
+        print(f"    {'  of which: bias reads (before the DMA issue)':42s} {np.median(extra - fine[:, 10]):6.2f}")
 life_us = t[:, 8] - t[:, 0]
 cyc = (buf[:, 15] - buf[:, 14]).astype(np.float64)
 print(f"  shader clock over wave life: median {np.median(cyc / life_us):.0f} MHz")
