@@ -62,27 +62,38 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 constexpr int kMaxOut = 8;
 
-struct PolicyArgs {
+constexpr int kMaxSlots = 8;           // observation tensors (grids) one launch can serve: tile flags carry the slot index
+
+// One observation tensor with the networks that read it and the buffers they write (oc_policy_forward: one;
+// oc_policy_forward_multi: one per layout of an engine group)
+struct PolicySlot {
     const uint8_t *packed;              // [n_nets][L.total]
-    oc_policy_layout L;                 // section offsets, identical for every network of the launch
+    oc_policy_layout L;                 // section offsets, identical for every network of the slot
     int n_nets;
+    int RB;                             // bytes per row = W*H*20
     const int8_t *obs;                  // [n_rows][RB]
     long long n_rows;
-    int RB;                             // bytes per row = W*H*20
-    const int4 *tiles;                  // {row0, nrows, net, flags}
-    int n_tiles;
-    int tile_per_wg;                    // 1: workgroup i owns tile i; 0: the table's blocks are split evenly over the grid
-    int desync;                         // experiment: the second wavefront of every SIMD starts this many x 64 cycles late
     float *raw;                         // [n_rows][n_out] raw head outputs (tiles without OC_POLICY_TILE_ACT)
     int32_t *actions;                   // [n_rows]
     float *action_logp;                 // [n_rows]
     float *logp;                        // [n_rows][n_out] or NULL
-    uint32_t seed, counter;
-    const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
     const int32_t *row_select;          // [n_rows] or NULL: tiles with a select code only write rows whose entry matches
+    uint32_t seed;
+    int pad_;
+};
+
+struct PolicyArgs {
+    PolicySlot slot[kMaxSlots];
+    int n_slots;
+    const int4 *tiles;                  // {row0, nrows, net, flags | slot << 16}
+    int n_tiles;
+    int tile_per_wg;                    // K >= 1: workgroup i owns tiles [i K, (i + 1) K) (empty ones skipped); 0: the table's blocks are split evenly over the grid
+    int desync;                         // experiment: the second wavefront of every SIMD starts this many x 64 cycles late
+    uint32_t counter;
+    const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
     int sample;                         // 0: argmax, 1: Gumbel-max draw
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
-    int lds_wave_bytes;                 // one wavefront's row-staging area
+    int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
 };
 
@@ -106,7 +117,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS-DMA loads: no VGPRs, so the copy for the NEXT block can be in flight under the dense layers of this one.
 // Pieces past the end of the tensor are skipped (their rows are never stored); the one piece that straddles the
 // end goes dword by dword.
-__device__ __forceinline__ void stage_rows(const PolicyArgs &a, uint8_t *ldsw, long long brow, int lane) {
+__device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, long long brow, int lane) {
     const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
     const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
     // Fast path: whole 1 KB instructions only.  The staging area is padded to a multiple of 1 KB (lds_wave_bytes), so the last
@@ -208,10 +219,10 @@ __device__ __forceinline__ v4i w1_from_l2(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 // stretch of blocks [wg0, wg1) that may run through several tiles (weights are reloaded only when the network changes along
 // it); a planned table -- about one balanced tile per CU, oc_policy_plan_tiles -- maps tile i to workgroup i instead.
 // Everything is wave-uniform.  Returns false when the workgroup has no block.
-__device__ __forceinline__ int policy_tile_blocks(const PolicyArgs &a, const int4 t) {
+__device__ __forceinline__ int policy_tile_blocks(const long long n_rows, const int4 t) {
     long long nr = t.y;
-    if (t.x < 0 || t.x >= a.n_rows || nr <= 0) return 0;              // a bad tile contributes nothing
-    if (t.x + nr > a.n_rows) nr = a.n_rows - t.x;
+    if (t.x < 0 || t.x >= n_rows || nr <= 0) return 0;              // a bad tile contributes nothing
+    if (t.x + nr > n_rows) nr = n_rows - t.x;
     return static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
 }
 
@@ -222,7 +233,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         const int i = base_tile + lane;
         int4 t = make_int4(0, 0, 0, 0);
         if (i < a.n_tiles) t = a.tiles[i];
-        nb = i < a.n_tiles ? policy_tile_blocks(a, t) : 0;
+        nb = i < a.n_tiles ? policy_tile_blocks(a.slot[0].n_rows, t) : 0;      // (launches over several slots are always tile-per-workgroup)
         incl = nb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -238,8 +249,16 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
             total += __builtin_amdgcn_readlane(incl, 63);
         }
     wg0 = a.tile_per_wg ? 0 : total * blockIdx.x / gridDim.x;
-    wg1 = a.tile_per_wg ? policy_tile_blocks(a, a.tiles[blockIdx.x]) : total * (blockIdx.x + 1) / gridDim.x;
-    ti = a.tile_per_wg ? static_cast<int>(blockIdx.x) : 0;
+    if (a.tile_per_wg) {
+        wg1 = 0;
+        for (int j = 0; j < a.tile_per_wg; ++j) {                    // (wave-uniform)
+            const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
+            wg1 += policy_tile_blocks(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0].n_rows, t);
+        }
+    } else {
+        wg1 = total * (blockIdx.x + 1) / gridDim.x;
+    }
+    ti = a.tile_per_wg ? static_cast<int>(blockIdx.x) * a.tile_per_wg : 0;
     tstart = 0;                                                       // first block of tile ti
     if (wg0 >= wg1) return false;
     if (!a.tile_per_wg)
@@ -260,7 +279,10 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
     return true;
 }
 
-template <int NDIG, bool FC1_LDS, bool CONV_LDS>
+// MULTI: the tile table runs over several slots (grids); everything that depends on the grid is then re-derived per tile.
+// Such launches keep the conv digits in registers and fc1 in L2 (the LDS-resident tail -- biases, fc2, head -- has the same
+// layout for every grid), and map workgroup i to tile i.
+template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false>
 __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
@@ -274,15 +296,18 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // are split EVENLY over the workgroups of the launch (one per CU), so a workgroup owns a contiguous stretch of
     // blocks that may run through several tiles.  Weights are (re)loaded only when the network changes along the
     // stretch.  Everything here is wave-uniform (scalar loads of the table).
-    auto tile_blocks = [&](const int4 t) -> int { return policy_tile_blocks(a, t); };
     long long wg0, wg1, tstart;
     int ti;
     if (!policy_find_stretch(a, lane, wg0, wg1, ti, tstart)) return;
 
-    const int RB = a.RB, P = a.L.P, PH = a.L.PH, H = a.L.H;
+    // grid-dependent values: of slot 0, or (MULTI) re-derived at every tile
+    int cur_slot = 0;
+    int RB = a.slot[0].RB, P = a.slot[0].L.P, PH = a.slot[0].L.PH, H = a.slot[0].L.H;
     const uint32_t counter = a.counter + (a.counter_ptr ? *a.counter_ptr : 0u);
-    const int wstart = static_cast<int>(FC1_LDS ? a.L.off_fc1 : a.L.off_b1);          // image offset of the LDS tail
-    const int conv_bytes = CONV_LDS ? static_cast<int>(a.L.off_fc1 - a.L.off_conv) : 0;
+    // image offset of the LDS tail (MULTI: off_b1 differs per slot, but everything behind it has the same layout)
+    int wstart = static_cast<int>(FC1_LDS ? a.slot[0].L.off_fc1 : a.slot[0].L.off_b1);
+    const oc_policy_layout &L0 = a.slot[0].L;
+    const int conv_bytes = CONV_LDS ? static_cast<int>(L0.off_fc1 - L0.off_conv) : 0;
     uint8_t *lds_tail = lds + conv_bytes;                                             // LDS address of image offset wstart
     // conv weight digits: [kx*2+s][digit] x 16 bytes per lane, read from LDS per use or (when the LDS is needed for
     // large rows) held in registers; conv scale / bias per accumulator register likewise
@@ -290,23 +315,23 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // conv bias in units of the channel's fixed-point scale (policy_pack.h): the lowest digit's accumulator starts from it
     v16i cbeta;
     const v4i *wcl = reinterpret_cast<const v4i *>(lds) + lane;
-    const v16i *cbeta_lds = reinterpret_cast<const v16i *>(lds + (a.L.off_conv_sb - a.L.off_conv) + 128 + h * 64);
+    const v16i *cbeta_lds = reinterpret_cast<const v16i *>(lds + (L0.off_conv_sb - L0.off_conv) + 128 + h * 64);
     // dense-layer weight fragments: 16 bytes (8 bf16) per lane and MFMA, fragment f of a section at [f * 64 + lane]
     // fc1 section of the network in global memory, as a buffer resource: scalar descriptor + scalar position offset + one
     // 32-bit lane offset per load (as plain pointers hipcc keeps twelve 64-bit vector addresses alive through the loop)
-    __amdgpu_buffer_rsrc_t w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.packed), 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.slot[0].packed), 0, 0, 0x00020000);
     const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
-    const v4i *w1l = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_fc1 - wstart)) + lane;
-    const float *b1 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b1 - wstart)) + h * 16;
-    const v4i *w2 = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_fc2 - wstart)) + lane;
-    const float *b2 = reinterpret_cast<const float *>(lds_tail + (a.L.off_b2 - wstart)) + h * 16;
+    const v4i *w1l = reinterpret_cast<const v4i *>(lds_tail + (L0.off_fc1 - wstart)) + lane;
+    const float *b1 = reinterpret_cast<const float *>(lds_tail + (L0.off_b1 - wstart)) + h * 16;
+    const v4i *w2 = reinterpret_cast<const v4i *>(lds_tail + (L0.off_fc2 - wstart)) + lane;
+    const float *b2 = reinterpret_cast<const float *>(lds_tail + (L0.off_b2 - wstart)) + h * 16;
     // head: only the outputs a < 8 are stored, [piece][k-group][8 h + a]; the other rows of the A operand are zero registers
     const bool head_lane = col < 8;
-    const v4i *wh = reinterpret_cast<const v4i *>(lds_tail + (a.L.off_head - wstart)) + (8 * h + (col & 7));
-    const float *bh = reinterpret_cast<const float *>(lds_tail + (a.L.off_bh - wstart)) + h * 4;
+    const v4i *wh = reinterpret_cast<const v4i *>(lds_tail + (L0.off_head - wstart)) + (8 * h + (col & 7));
+    const float *bh = reinterpret_cast<const float *>(lds_tail + (L0.off_bh - wstart)) + h * 4;
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
-    const int colstep = H * OC_POLICY_C;
-    int loaded_net = -1, n_out = 1;
+    int colstep = H * OC_POLICY_C;
+    int loaded_net = -1, loaded_slot = 0, n_out = 1;
     bool trace_done = false, trace2_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
@@ -368,22 +393,31 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
 
   for (long long cur = wg0; cur < wg1;) {
     const int4 tile = a.tiles[ti];
-    const int tnb = tile_blocks(tile);
+    if (MULTI) {
+        cur_slot = __builtin_amdgcn_readfirstlane((tile.w >> 16) & (kMaxSlots - 1));
+        const PolicySlot &T = a.slot[cur_slot];
+        RB = T.RB; P = T.L.P; PH = T.L.PH; H = T.L.H;
+        colstep = H * OC_POLICY_C;
+        rowp = ldsw + col * RB + 16 * h;
+        wstart = static_cast<int>(T.L.off_b1);
+    }
+    const PolicySlot &S = a.slot[MULTI ? cur_slot : 0];
+    const int tnb = policy_tile_blocks(S.n_rows, tile);
     if (tnb == 0) { ++ti; continue; }
     const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
     const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);   // this stretch of the tile
     const long long row0 = tile.x;
-    const int nrows = static_cast<int>(row0 + tile.y > a.n_rows ? a.n_rows - row0 : tile.y);
-    const int net = min(max(tile.z, 0), a.n_nets - 1);
+    const int nrows = static_cast<int>(row0 + tile.y > S.n_rows ? S.n_rows - row0 : tile.y);
+    const int net = min(max(tile.z, 0), S.n_nets - 1);
     const int flags = tile.w;
     cur = run_end;
     if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
 
     // this wavefront's first block of the stretch: in flight while (if) the weights are fetched
-    if (first + wave < last) stage_rows(a, ldsw, row0 + static_cast<long long>(first + wave) * kRowsPerBlock, lane);
-    if (net != loaded_net) {
+    if (first + wave < last) stage_rows(S, ldsw, row0 + static_cast<long long>(first + wave) * kRowsPerBlock, lane);
+    if (net != loaded_net || (MULTI && cur_slot != loaded_slot)) {
         __syncthreads();                                              // everybody is done with the previous network
-        const uint8_t *blob = a.packed + static_cast<size_t>(net) * a.L.total;
+        const uint8_t *blob = S.packed + static_cast<size_t>(net) * S.L.total;
         n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
         // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the
         // tail from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once
@@ -393,23 +427,24 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
                 const int i = i0 + lane;
                 if (i < n16) {
-                    const uint8_t *src = i < n16c ? blob + a.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
+                    const uint8_t *src = i < n16c ? blob + S.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
                 }
             }
         }
         if (!CONV_LDS) {
-            const v4i *src = reinterpret_cast<const v4i *>(blob + a.L.off_conv);
+            const v4i *src = reinterpret_cast<const v4i *>(blob + S.L.off_conv);
 #pragma unroll
             for (int ks = 0; ks < (CONV_LDS ? 1 : 6); ++ks)
 #pragma unroll
                 for (int d = 0; d < NDIG; ++d) wA[ks][d] = src[(ks * NDIG + d) * 64 + lane];
-            cbeta = *reinterpret_cast<const v16i *>(blob + a.L.off_conv_sb + 128 + h * 64);
+            cbeta = *reinterpret_cast<const v16i *>(blob + S.L.off_conv_sb + 128 + h * 64);
         }
-        w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(blob + a.L.off_fc1), 0, P * OC_POLICY_FC1_POS_BYTES, 0x00020000);
+        w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(blob + S.L.off_fc1), 0, P * OC_POLICY_FC1_POS_BYTES, 0x00020000);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's share of the weight copy has landed
         __syncthreads();                                              // the network is in LDS
         loaded_net = net;
+        loaded_slot = cur_slot;
         stamp(a, wave, lane, 1);
         if (a.desync && wave >= 4)                                    // experiment: break the lock-step of a SIMD's two waves
             for (int i = 0; i < a.desync; i += 100) __builtin_amdgcn_s_sleep(100);
@@ -429,11 +464,11 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (traced2) stamp(a, wave, lane, 17);
         // A tile with a select code skips the blocks none of whose rows it would write (mixed play: the stretch of
         // kitchens already forced onto the other policy costs this network nothing).
-        if (((flags >> 8) & 0xff) && a.row_select) {
+        if (((flags >> 8) & 0xff) && S.row_select) {
             const int want = ((flags >> 8) & 0xff) - 1;
-            const bool mine = col + blk * kRowsPerBlock < nrows && a.row_select[brow + col] == want;
+            const bool mine = col + blk * kRowsPerBlock < nrows && S.row_select[brow + col] == want;
             if (__ballot(mine) == 0) {
-                if (blk + nwaves < last) stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+                if (blk + nwaves < last) stage_rows(S, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
                 continue;
             }
         }
@@ -546,7 +581,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         // the wavefront for its ~0.1 us, the time just moves there: 99.4 vs 95.2 us per cramped_room launch)
         wave_lds_sync();
         if (blk + nwaves < last)
-            stage_rows(a, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+            stage_rows(S, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 27);
 
@@ -614,12 +649,12 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         const long long row = brow + col;
         bool valid = (blk * kRowsPerBlock + col) < nrows;
         const int sel = (flags >> 8) & 0xff;                          // OC_POLICY_TILE_SELECT(v): only rows with row_select == v
-        if (sel && a.row_select && valid) valid = a.row_select[row] == sel - 1;
+        if (sel && S.row_select && valid) valid = S.row_select[row] == sel - 1;
         if (!(flags & OC_POLICY_TILE_ACT)) {
-            if (valid && a.raw) {
+            if (valid && S.raw) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * h + r < n_out) a.raw[row * n_out + 4 * h + r] = out[r];
+                    if (4 * h + r < n_out) S.raw[row * n_out + 4 * h + r] = out[r];
             }
             continue;
         }
@@ -645,11 +680,11 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 const float lp = out[r] - lse;
                 float key = lp;
                 if (a.sample) {                                       // the noise needs no more than the fast logarithm
-                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(a.seed, counter, static_cast<uint32_t>(row), i));
+                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), i));
                     key = lp - __logf(-__logf(u));
                 }
                 if (key > best_key) { best_key = key; best = i; best_lp = lp; }
-                if (valid && a.logp) a.logp[row * n_out + i] = lp;
+                if (valid && S.logp) S.logp[row * n_out + i] = lp;
             }
         }
         {
@@ -658,8 +693,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
         }
         if (valid && h == 0) {
-            if (a.actions) a.actions[row] = best;
-            if (a.action_logp) a.action_logp[row] = best_lp;
+            if (S.actions) S.actions[row] = best;
+            if (S.action_logp) S.action_logp[row] = best_lp;
         }
         if (traced) stamp(a, wave, lane, 7);
         if (traced2) stamp(a, wave, lane, 30);
@@ -731,35 +766,48 @@ int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const fl
     return OC_OK;
 }
 
-int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
-                             int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity) {
+}  // extern "C"
+
+namespace {
+
+// seg_slot / slot_cost: NULL for a single grid; otherwise the slot of each segment and the relative cost of one 32-row block of
+// each slot (the balanced plan then evens out cost, not block counts, and the tiles carry the slot in their flags).
+int64_t plan_tiles_impl(const char *who, const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
+                        const int32_t *seg_slot, const float *slot_cost, int32_t n_slots, int32_t n_segs, int32_t rows_per_tile,
+                        int32_t *host_tiles, int64_t capacity) {
     const bool balanced = rows_per_tile < 0;                          // -rows_per_tile = number of workgroups to fill
     if (!seg_row0 || !seg_rows || !seg_net || n_segs < 0 || rows_per_tile == 0 ||
         (!balanced && (rows_per_tile < kRowsPerBlock || rows_per_tile % kRowsPerBlock)))
-        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: bad arguments (rows_per_tile: a multiple of %d, or -workgroups)", kRowsPerBlock);
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: bad arguments (rows_per_tile: a multiple of %d, or -workgroups)", who, kRowsPerBlock);
     std::vector<int64_t> blocks(n_segs), pieces(n_segs);
-    int64_t total = 0;
+    std::vector<double> cost(n_segs, 1.0);
+    double total = 0;
     for (int32_t g = 0; g < n_segs; ++g) {
         if (seg_row0[g] < 0 || seg_rows[g] < 0 || seg_row0[g] + seg_rows[g] > INT32_MAX)
-            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: segment %d out of range", g);
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: segment %d out of range", who, g);
+        if (seg_slot) {
+            if (seg_slot[g] < 0 || seg_slot[g] >= n_slots || !(slot_cost[seg_slot[g]] > 0.f))
+                return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: segment %d names slot %d (of %d) or a non-positive cost", who, g, seg_slot[g], n_slots);
+            cost[g] = slot_cost[seg_slot[g]];
+        }
         blocks[g] = (seg_rows[g] + kRowsPerBlock - 1) / kRowsPerBlock;
-        total += blocks[g];
+        total += blocks[g] * cost[g];
     }
     if (balanced) {
         // One tile = one workgroup = one network, so no workgroup reloads weights.  Pieces per segment in proportion
-        // to its 32-row blocks, then the spare workgroups go, one at a time, to the segment with the largest pieces.
+        // to its work, then the spare workgroups go, one at a time, to the segment with the most expensive pieces.
         const int64_t wgs = -static_cast<int64_t>(rows_per_tile);
         int64_t used = 0;
         for (int32_t g = 0; g < n_segs; ++g) {
-            pieces[g] = blocks[g] == 0 ? 0 : std::max<int64_t>(1, std::min(blocks[g], total ? wgs * blocks[g] / total : 1));
+            pieces[g] = blocks[g] == 0 ? 0 : std::max<int64_t>(1, std::min(blocks[g], total > 0 ? static_cast<int64_t>(wgs * (blocks[g] * cost[g]) / total) : 1));
             used += pieces[g];
         }
         for (; used < wgs; ++used) {
             int32_t best = -1;
-            double worst = 1.0;                                       // only segments whose pieces exceed one block
+            double worst = 0.0;                                       // only segments whose pieces exceed one block
             for (int32_t g = 0; g < n_segs; ++g)
-                if (pieces[g] > 0 && pieces[g] < blocks[g] && static_cast<double>(blocks[g]) / pieces[g] > worst) {
-                    worst = static_cast<double>(blocks[g]) / pieces[g];
+                if (pieces[g] > 0 && pieces[g] < blocks[g] && static_cast<double>(blocks[g]) / pieces[g] * cost[g] > worst) {
+                    worst = static_cast<double>(blocks[g]) / pieces[g] * cost[g];
                     best = g;
                 }
             if (best < 0) break;
@@ -776,13 +824,92 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
             const int64_t r = done_blocks * kRowsPerBlock, left = seg_rows[g] - r;
             done_blocks += nb;
             if (!host_tiles) continue;
-            if (n >= capacity) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles: capacity %lld too small", (long long)capacity);
+            if (n >= capacity) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: capacity %lld too small", who, (long long)capacity);
             host_tiles[4 * n + 0] = static_cast<int32_t>(seg_row0[g] + r);
             host_tiles[4 * n + 1] = static_cast<int32_t>(std::min(left, nb * kRowsPerBlock));
             host_tiles[4 * n + 2] = seg_net[g];
-            host_tiles[4 * n + 3] = seg_flags ? seg_flags[g] : 0;
+            host_tiles[4 * n + 3] = ((seg_flags ? seg_flags[g] : 0) & 0xFFFF) | (seg_slot ? seg_slot[g] << 16 : 0);
         }
     }
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
+                             int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity) {
+    return plan_tiles_impl("oc_policy_plan_tiles", seg_row0, seg_rows, seg_net, seg_flags, nullptr, nullptr, 1, n_segs, rows_per_tile, host_tiles, capacity);
+}
+
+int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
+                                   const int32_t *seg_slot, const float *slot_cost, int32_t n_slots, int32_t n_segs, int32_t workgroups,
+                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup) {
+    if (!seg_row0 || !seg_rows || !seg_net || !seg_slot || !slot_cost || !tiles_per_workgroup || n_slots < 1 || n_slots > kMaxSlots ||
+        workgroups < 1 || n_segs < 0)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: NULL pointer, 1..%d slots with their costs, workgroups >= 1", kMaxSlots);
+    // Fewer segments than workgroups: the single-grid plan with costs -- workgroups shared out over the segments in proportion
+    // to their work, one tile each, no workgroup ever changes network (config 3's actors: 96 us per joint step against 103 packed).
+    {
+        int32_t live = 0;
+        for (int32_t g = 0; g < n_segs; ++g) live += seg_rows[g] > 0 ? 1 : 0;
+        if (live <= workgroups) {
+            *tiles_per_workgroup = 1;
+            return plan_tiles_impl("oc_policy_plan_tiles_multi", seg_row0, seg_rows, seg_net, seg_flags, seg_slot, slot_cost, n_slots, n_segs,
+                                   -workgroups, host_tiles, capacity);
+        }
+    }
+    // Otherwise: the 32-row blocks of all segments, in order, form one sequence with a cost each; workgroup w takes the blocks whose
+    // cost midpoint falls into [w, w + 1) x (total cost / workgroups): equal work whatever the number and size of the segments
+    // (one tile per workgroup, as the single-grid plan has it, stops balancing once there are more segments than workgroups:
+    // config 5 has 1260).  A segment that spans a boundary is cut there; a workgroup whose stretch runs through several segments
+    // reloads the weights at each.  The table holds `*tiles_per_workgroup` entries per workgroup, padded with empty tiles.
+    std::vector<int64_t> blocks(n_segs);
+    std::vector<double> cost(n_segs);
+    double total = 0;
+    for (int32_t g = 0; g < n_segs; ++g) {
+        if (seg_row0[g] < 0 || seg_rows[g] < 0 || seg_row0[g] + seg_rows[g] > INT32_MAX)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: segment %d out of range", g);
+        if (seg_slot[g] < 0 || seg_slot[g] >= n_slots || !(slot_cost[seg_slot[g]] > 0.f))
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: segment %d names slot %d (of %d) or a non-positive cost", g, seg_slot[g], n_slots);
+        cost[g] = slot_cost[seg_slot[g]];
+        blocks[g] = (seg_rows[g] + kRowsPerBlock - 1) / kRowsPerBlock;
+        total += blocks[g] * cost[g];
+    }
+    const double share = total > 0 ? total / workgroups : 1.0;
+    auto owner = [&](double mid) { return std::min<int64_t>(workgroups - 1, static_cast<int64_t>(mid / share)); };
+    struct Piece { int32_t seg; int64_t b0, nb; };
+    std::vector<std::vector<Piece>> of_wg(workgroups);
+    double x = 0;
+    for (int32_t g = 0; g < n_segs; ++g) {
+        int64_t j = 0;
+        while (j < blocks[g]) {
+            const int64_t w = owner(x + (j + 0.5) * cost[g]);
+            int64_t e = j + 1;                                        // extend while the owner stays the same
+            while (e < blocks[g] && owner(x + (e + 0.5) * cost[g]) == w) ++e;
+            of_wg[w].push_back(Piece{g, j, e - j});
+            j = e;
+        }
+        x += blocks[g] * cost[g];
+    }
+    size_t per = 1;
+    for (const auto &v : of_wg) per = std::max(per, v.size());
+    *tiles_per_workgroup = static_cast<int32_t>(per);
+    const int64_t n = static_cast<int64_t>(per) * workgroups;
+    if (!host_tiles) return n;
+    if (n > capacity) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: capacity %lld too small", (long long)capacity);
+    memset(host_tiles, 0, static_cast<size_t>(n) * 4 * sizeof(int32_t));
+    for (int64_t w = 0; w < workgroups; ++w)
+        for (size_t i = 0; i < of_wg[w].size(); ++i) {
+            const Piece &pc = of_wg[w][i];
+            int32_t *t = host_tiles + 4 * (w * static_cast<int64_t>(per) + static_cast<int64_t>(i));
+            const int64_t r = pc.b0 * kRowsPerBlock;
+            t[0] = static_cast<int32_t>(seg_row0[pc.seg] + r);
+            t[1] = static_cast<int32_t>(std::min(seg_rows[pc.seg] - r, pc.nb * kRowsPerBlock));
+            t[2] = seg_net[pc.seg];
+            t[3] = ((seg_flags ? seg_flags[pc.seg] : 0) & 0xFFFF) | (seg_slot[pc.seg] << 16);
+        }
     return n;
 }
 
@@ -794,38 +921,42 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                                  seed, counter, d_counter, d_row_select, 0, stream);
 }
 
-int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
-                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
-                          const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+}  // extern "C"
+
+namespace {
+
+// Fill one slot of the launch arguments (argument checks shared by the single- and the multi-grid entry points).
+int fill_slot(PolicySlot &t, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+              float *d_raw, int32_t *d_actions, float *d_action_logp, float *d_logp, const int32_t *d_row_select, uint32_t seed) {
     if (int rc = check_shape(shape, "oc_policy_forward")) return rc;
-    if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
-    if (!d_packed || !d_obs || !d_tiles || n_nets < 1 || n_rows < 1 || n_tiles < 0)
-        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
-    if ((reinterpret_cast<uintptr_t>(d_packed) & 15) || (reinterpret_cast<uintptr_t>(d_obs) & 3) || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
-        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_packed / d_tiles must be 16-byte aligned, d_obs 4-byte aligned");
+    if (!d_packed || !d_obs || n_nets < 1 || n_rows < 1) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: NULL pointer or empty input");
+    if ((reinterpret_cast<uintptr_t>(d_packed) & 15) || (reinterpret_cast<uintptr_t>(d_obs) & 3))
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_packed must be 16-byte aligned, d_obs 4-byte aligned");
     if (n_rows > INT32_MAX) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: more than 2^31 rows");
-    if (sample_mode != 0 && sample_mode != 1) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: sample_mode %d", sample_mode);
-    if (n_tiles == 0) return OC_OK;
-    PolicyArgs a;
-    a.packed = static_cast<const uint8_t *>(d_packed);
-    a.L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
-    a.n_nets = n_nets;
-    a.obs = d_obs;
-    a.n_rows = n_rows;
-    a.RB = shape->width * shape->height * OC_POLICY_C;
-    if (n_rows * a.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
-    a.tiles = reinterpret_cast<const int4 *>(d_tiles);
-    a.n_tiles = n_tiles;
-    a.raw = d_raw; a.actions = d_actions; a.action_logp = d_action_logp; a.logp = d_logp;
-    a.seed = seed; a.counter = counter; a.counter_ptr = d_counter; a.row_select = d_row_select; a.sample = sample_mode;
+    t.packed = static_cast<const uint8_t *>(d_packed);
+    t.L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
+    t.n_nets = n_nets;
+    t.RB = shape->width * shape->height * OC_POLICY_C;
+    t.obs = d_obs;
+    t.n_rows = n_rows;
+    if (n_rows * t.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
+    t.raw = d_raw; t.actions = d_actions; t.action_logp = d_action_logp; t.logp = d_logp; t.row_select = d_row_select;
+    t.seed = seed;
+    t.pad_ = 0;
+    return OC_OK;
+}
+
+int staging_bytes(int RB) { return (kRowsPerBlock * RB + 16 + 1023) / 1024 * 1024; }   // whole 1 KB LDS-DMA instructions (stage_rows)
+
+// Pick the LDS plan and launch.  `multi`: the tile table runs over a.n_slots grids.
+int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipStream_t stream) {
+    const PolicySlot &s0 = a.slot[0];
     a.trace = g_trace;
-    a.lds_wave_bytes = (kRowsPerBlock * a.RB + 16 + 1023) / 1024 * 1024;      // whole 1 KB LDS-DMA instructions (stage_rows)
-    // LDS plan: 4 wavefronts (one per SIMD) with every dense-layer weight resident if that fits the 160 KB of a
-    // CU; otherwise fc1 (12 KB per conv position) stays in L2 and is prefetched into registers per position.
+    a.lds_wave_bytes = 0;
+    for (int i = 0; i < a.n_slots; ++i) a.lds_wave_bytes = std::max(a.lds_wave_bytes, staging_bytes(a.slot[i].RB));
     constexpr long long kLds = 160 * 1024;
-    const long long w_tail_all = a.L.off_bh + 32 - a.L.off_fc1, w_tail_small = a.L.off_bh + 32 - a.L.off_b1;
-    const long long w_conv = a.L.off_fc1 - a.L.off_conv, obs1 = a.lds_wave_bytes;
+    const long long w_tail_all = s0.L.off_bh + 32 - s0.L.off_fc1, w_tail_small = s0.L.off_bh + 32 - s0.L.off_b1;
+    const long long w_conv = s0.L.off_fc1 - s0.L.off_conv, obs1 = a.lds_wave_bytes;
     // Plan (profiles/r02_policy_plan_sweep.log):
     //   8 wavefronts (two per SIMD, 256 registers each) when eight staging areas fit next to the conv digits and the small
     //   tail: fc1 (12 KB per position) is then prefetched from L2 one position ahead (cramped_room: 102 us for 245 760
@@ -833,12 +964,13 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     //   otherwise 4 wavefronts (one per SIMD, 512 registers) with the conv digits in REGISTERS -- at one wavefront per SIMD the
     //   24 LDS fragment reads per position are latency nobody hides (counter_circuit 133 vs 147 us, forced_coordination 134
     //   vs 156) -- and fc1 LDS-resident if that fits, else from L2; then fewer wavefronts for very large rows.
+    //   Several grids in one launch: the four-wavefront plan with fc1 in L2 (the LDS image is then the same for every grid).
     int waves = 8;
     bool fc1_lds = false, conv_lds = true;
-    if (w_conv + w_tail_small + 8 * obs1 > kLds) {
+    if (multi || w_conv + w_tail_small + 8 * obs1 > kLds) {
         waves = 4;
         conv_lds = false;
-        fc1_lds = w_tail_all + 4 * obs1 <= kLds;
+        fc1_lds = !multi && w_tail_all + 4 * obs1 <= kLds;
     }
     // Two cooperative plans for the grids where eight staging areas do not fit were built and measured in round 2 -- two
     // wavefronts of a SIMD sharing one staged block and splitting its conv positions, and a conv-wavefront / dense-wavefront
@@ -847,29 +979,32 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     // on one gfx950 SIMD a partner wavefront's VALU work does not overlap back-to-back MFMAs of any type (both together cost
     // the sum, not the maximum), so a second wavefront per SIMD can only fill MFMA-free gaps, not hide work.
     const char *const env_plan = getenv("OC_POLICY_PLAN");           // diagnostics: "waves,fc1_lds,conv_lds" (read per call)
-    if (env_plan && env_plan[0]) {
+    if (env_plan && env_plan[0] && !multi) {
         int w = 0, f = 0, c = 0;
         if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
     a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
     const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
-    if (lds > static_cast<size_t>(kLds)) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.RB);
+    if (lds > static_cast<size_t>(kLds))
+        return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.lds_wave_bytes / kRowsPerBlock);
     typedef void (*kernel_t)(const PolicyArgs);
     static const kernel_t kernels[4][2][2] = {
         {{oc_policy_kernel<1, false, false>, oc_policy_kernel<1, false, true>}, {oc_policy_kernel<1, true, false>, oc_policy_kernel<1, true, true>}},
         {{oc_policy_kernel<2, false, false>, oc_policy_kernel<2, false, true>}, {oc_policy_kernel<2, true, false>, oc_policy_kernel<2, true, true>}},
         {{oc_policy_kernel<3, false, false>, oc_policy_kernel<3, false, true>}, {oc_policy_kernel<3, true, false>, oc_policy_kernel<3, true, true>}},
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
-    const kernel_t kernel = kernels[shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    static const kernel_t kernels_multi[4] = {oc_policy_kernel<1, false, false, true>, oc_policy_kernel<2, false, false, true>,
+                                              oc_policy_kernel<3, false, false, true>, oc_policy_kernel<4, false, false, true>};
+    const kernel_t kernel = multi ? kernels_multi[digits - 1] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
-    int dev = oc_device_of_pointer(d_packed);
+    int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2] = {};                      // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][shape->digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    static size_t lds_granted[64][4][2][2][2] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][multi ? 1 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -889,16 +1024,68 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     // (more tiles than CUs -- many segments on a small CU share -- would need a second round of workgroups: split evenly instead)
-    a.tile_per_wg = (n_tiles >= n_cus / 2 && n_tiles <= n_cus) ? 1 : 0;
+    // Several grids: workgroup i owns tile_per_wg consecutive entries of the table (oc_policy_plan_tiles_multi).
+    if (!multi) a.tile_per_wg = (a.n_tiles >= n_cus / 2 && a.n_tiles <= n_cus) ? 1 : 0;
     static const char *const env_desync = getenv("OC_POLICY_DESYNC");
     a.desync = env_desync ? atoi(env_desync) : 0;
-    int grid = a.tile_per_wg ? n_tiles : n_cus;
+    int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
     static const char *const env_grid = getenv("OC_POLICY_GRID");
     if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
     return OC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                          const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+    if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
+    if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_tiles NULL or not 16-byte aligned");
+    if (sample_mode != 0 && sample_mode != 1) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: sample_mode %d", sample_mode);
+    PolicyArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int rc = fill_slot(a.slot[0], shape, d_packed, n_nets, d_obs, n_rows, d_raw, d_actions, d_action_logp, d_logp, d_row_select, seed)) return rc;
+    if (n_tiles == 0) return OC_OK;
+    a.n_slots = 1;
+    a.tiles = reinterpret_cast<const int4 *>(d_tiles);
+    a.n_tiles = n_tiles;
+    a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
+    return launch_policy(a, shape->digits, false, cu_budget, static_cast<hipStream_t>(stream));
+}
+
+int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
+                            int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream) {
+    if (!slots || n_slots < 1 || n_slots > kMaxSlots)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: 1..%d slots", kMaxSlots);
+    if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15) || tiles_per_workgroup < 1 || n_tiles % tiles_per_workgroup)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: d_tiles NULL / not 16-byte aligned, or n_tiles not a multiple of tiles_per_workgroup");
+    if (sample_mode != 0 && sample_mode != 1) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: sample_mode %d", sample_mode);
+    PolicyArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n_slots; ++i) {
+        const oc_policy_multi_slot &m = slots[i];
+        if (int rc = fill_slot(a.slot[i], m.shape, m.d_packed, m.n_nets, m.d_obs, m.n_rows, m.d_raw, m.d_actions, m.d_action_logp, m.d_logp,
+                               m.d_row_select, m.seed))
+            return rc;
+        if (m.shape->digits != slots[0].shape->digits)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: every slot's networks must use the same number of conv digits");
+        if (oc_device_of_pointer(m.d_packed) != oc_device_of_pointer(slots[0].d_packed))
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: slot %d lives on another device", i);
+    }
+    if (n_tiles == 0) return OC_OK;
+    a.n_slots = n_slots;
+    a.tiles = reinterpret_cast<const int4 *>(d_tiles);
+    a.n_tiles = n_tiles;
+    a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
+    a.tile_per_wg = tiles_per_workgroup;
+    return launch_policy(a, slots[0].shape->digits, true, 0, static_cast<hipStream_t>(stream));
 }
 
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
@@ -1073,6 +1260,51 @@ int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void
     cleanup();
     if (rc == OC_OK && he != hipSuccess) rc = oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: join failed: %s", hipGetErrorString(he));
     return rc;
+}
+
+int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
+                                  int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
+    const int n = oc_group_size(g);
+    if (n < 1 || n > kMaxSlots || !slots || !d_tiles || T < 0)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: NULL group / slots / tiles, negative T or more than %d engines", kMaxSlots);
+    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n);
+    for (int i = 0; i < n; ++i) {
+        int64_t shp[5];
+        if (int rc = oc_obs_shape(oc_internal_group_engine(g, i), shp)) return rc;
+        const oc_group_policy_slot &s = slots[i];
+        if (!s.shape || !s.d_packed || !s.d_obs || !s.d_actions || !s.d_reward || !s.d_done)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: NULL pointer in slot %d", i);
+        if (shp[0] != 2 || shp[2] != s.shape->width || shp[3] != s.shape->height)
+            return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: the networks' grid of slot %d does not match its (2-player) engine's", i);
+        kitchens[i] = shp[1]; rows[i] = 2 * shp[1]; slot_bytes[i] = rows[i] * shp[2] * shp[3] * shp[4];
+    }
+    const OcDeviceScope on_device(oc_device_id(oc_internal_group_engine(g, 0)));
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout_multi: cannot make the group's device current");
+    std::vector<oc_policy_multi_slot> ms(n);
+    std::vector<const void *> act(n);
+    std::vector<int8_t *> obs_next(n);
+    std::vector<int32_t *> rew(n), done(n);
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t k = in_place ? 0 : t;
+        for (int i = 0; i < n; ++i) {
+            const oc_group_policy_slot &s = slots[i];
+            oc_policy_multi_slot &m = ms[i];
+            m.shape = s.shape; m.d_packed = s.d_packed; m.n_nets = s.n_nets;
+            m.d_obs = s.d_obs + k * slot_bytes[i]; m.n_rows = rows[i];
+            m.d_raw = s.d_values ? s.d_values + k * rows[i] : nullptr;
+            m.d_actions = s.d_actions + k * rows[i];
+            m.d_action_logp = s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr;
+            m.d_logp = nullptr; m.d_row_select = nullptr;
+            m.seed = seed + static_cast<uint32_t>(i) * 0x9E3779B9u;      // as oc_group_policy_rollout draws them
+            act[i] = m.d_actions;
+            obs_next[i] = in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i];
+            rew[i] = s.d_reward + k * rows[i];
+            done[i] = s.d_done + k * kitchens[i];
+        }
+        if (int rc = oc_policy_forward_multi(ms.data(), n, d_tiles, n_tiles, tiles_per_workgroup, sample_mode, counter0 + static_cast<uint32_t>(t), nullptr, stream)) return rc;
+        if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream)) return rc;
+    }
+    return OC_OK;
 }
 
 /* Diagnostics, deliberately not in the public header: per-wavefront phase stamps of the following launches

@@ -176,6 +176,83 @@ class PolicyPlan:
                                                     int(counter) & 0xFFFFFFFF, _ptr(device_counter), _ptr(row_select), _stream(nets.device)))
 
 
+def tile_slot(i):
+    """OC_POLICY_TILE_SLOT(i): the tile belongs to slot (grid) i of a multi-grid launch."""
+    return (int(i) & 7) << 16
+
+
+class MultiPolicyPlan:
+    """ONE launch over several observation tensors of different grids (`oc_policy_forward_multi`): the layouts of an engine
+    group.  Five per-layout launches cannot share a CU (each fills its registers and LDS), so at 8192 kitchens per layout they
+    leave half the SIMDs without a 32-row block; one tile table balanced by block cost does not.
+
+    nets[i]: PackedNetworks of grid i; n_rows[i]; segments[i]: (row0, rows, net, flags) inside grid i."""
+
+    def __init__(self, nets: Sequence[PackedNetworks], n_rows: Sequence[int], segments, workgroups: Optional[int] = None):
+        self.nets, self.n_rows = list(nets), [int(n) for n in n_rows]
+        if not 1 <= len(self.nets) <= 8 or len(self.n_rows) != len(self.nets) or len(segments) != len(self.nets):
+            raise ValueError("1..8 grids, with one row count and one segment list each")
+        dev = self.nets[0].device
+        if any(nt.device != dev or nt.digits != self.nets[0].digits for nt in self.nets):
+            raise ValueError("all grids' networks must live on one device and use the same number of conv digits")
+        rows = []
+        for i, (nt, n, segs) in enumerate(zip(self.nets, self.n_rows, segments)):
+            for row0, cnt, net, flags in segs:
+                if row0 < 0 or cnt < 0 or row0 + cnt > n or not 0 <= net < nt.n_nets:
+                    raise ValueError(f"grid {i}: segment ({row0}, {cnt}, net {net}) outside {n} rows / {nt.n_nets} networks")
+                rows.append((int(row0), int(cnt), int(net), int(flags), i))
+        seg = np.asarray(rows, dtype=np.int64).reshape(-1, 5)
+        cols = [np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1])] + [np.ascontiguousarray(seg[:, j].astype(np.int32)) for j in (2, 3, 4)]
+        # relative cost of a 32-row block: conv positions + the position-independent part (DESIGN.md 9a, measured launches)
+        cost = np.asarray([(nt.W - 2) * (nt.H - 2) + 2.5 for nt in self.nets], dtype=np.float32)
+        if workgroups is None:
+            workgroups = torch.cuda.get_device_properties(dev).multi_processor_count
+        self.workgroups = int(workgroups)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        L = native.lib()
+        args = [p(c) for c in cols] + [p(cost), len(self.nets), len(seg), self.workgroups]
+        per = ctypes.c_int32(0)
+        n = L.oc_policy_plan_tiles_multi(*args, None, 0, ctypes.byref(per))
+        if n < 0:
+            native.check(int(n))
+        tiles = np.zeros((max(int(n), 1), 4), dtype=np.int32)
+        n2 = L.oc_policy_plan_tiles_multi(*args, p(tiles), int(n), ctypes.byref(per))
+        if n2 < 0:
+            native.check(int(n2))
+        self.tiles = torch.from_numpy(tiles[:int(n)]).to(dev)
+        self.n_tiles, self.tiles_per_workgroup = int(n), int(per.value)
+        self.counter = 0
+        self._shapes = [_shape(nt.W, nt.H, 6, nt.digits) for nt in self.nets]
+
+    def forward(self, obs, raw=None, actions=None, action_logp=None, logp=None, row_select=None, deterministic=False, seeds=None, counter=None,
+                device_counter=None):
+        """Per-grid lists: obs[i] contiguous int8 with n_rows[i] rows; outputs as PolicyPlan.forward takes them (None or lists)."""
+        k = len(self.nets)
+        none = [None] * k
+        raw, actions, action_logp, logp, row_select = (x if x is not None else none for x in (raw, actions, action_logp, logp, row_select))
+        seeds = [0] * k if seeds is None else list(seeds)
+        slots = (native.OcPolicyMultiSlot * k)()
+        for i, nt in enumerate(self.nets):
+            rb = nt.W * nt.H * 20
+            if obs[i].dtype != torch.int8 or not obs[i].is_contiguous() or obs[i].device != nt.device or obs[i].numel() != self.n_rows[i] * rb:
+                raise ValueError(f"obs[{i}] must be a contiguous int8 tensor of {self.n_rows[i]} rows x {rb} bytes on {nt.device}")
+            for name, t, dt in (("raw", raw[i], torch.float32), ("actions", actions[i], torch.int32), ("action_logp", action_logp[i], torch.float32),
+                                ("logp", logp[i], torch.float32), ("row_select", row_select[i], torch.int32)):
+                if t is not None and (t.dtype != dt or not t.is_contiguous() or t.device != nt.device):
+                    raise ValueError(f"{name}[{i}] must be a contiguous {dt} tensor on {nt.device}")
+            s = slots[i]
+            s.shape = ctypes.pointer(self._shapes[i])
+            s.d_packed, s.n_nets, s.d_obs, s.n_rows = _ptr(nt.image), nt.n_nets, _ptr(obs[i]), self.n_rows[i]
+            s.d_raw, s.d_actions, s.d_action_logp, s.d_logp, s.d_row_select = (_ptr(raw[i]), _ptr(actions[i]), _ptr(action_logp[i]), _ptr(logp[i]),
+                                                                              _ptr(row_select[i]))
+            s.seed = int(seeds[i]) & 0xFFFFFFFF
+        if counter is None:
+            counter, self.counter = self.counter, self.counter + 1
+        dev = self.nets[0].device
+        native.check(native.lib().oc_policy_forward_multi(slots, k, _ptr(self.tiles), self.n_tiles, self.tiles_per_workgroup,
+                                                          0 if deterministic else 1, int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(dev)))
+
+
 def gumbel_uniform(seed, counter, row, action):
     """The uniform the kernel used for (row, action) of a draw: lets a test re-derive every sampled action."""
     return float(native.lib().oc_policy_uniform(int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, int(row), int(action)))

@@ -116,23 +116,28 @@ class GroupPairedRollout:
     this as five simulators and 5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26,
     train/XD/xd_player.py:190-207).  Kitchens of different engines never interact, so the engines need not march in step:
 
-    partition="streams" (default): every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
+    partition="auto" (default): "one_launch" when every pairing segment holds at least 256 kitchens, else "streams".
+    partition="streams": every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
         own stream, side by side with the others, no synchronisation between engines: one fork, one join per call.
-        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 173 us per joint step, 247 us with critics; config 5's
-        (32 conventions, 63 segments, critics): 298 us (profiles/r02_bench_group_policies.log).
+        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 130 us per joint step, 180 us with critics; config 5's
+        (32 conventions, 63 segments, critics): 208 us (profiles/r02_bench_group_policies.log).
     partition=False: everything on the current stream -- the policy launches one after the other, then ONE env launch for all
-        engines (`oc_group_step`): 186 / 315 us; the env launch saved is worth less than the overlap lost.
+        engines (`oc_group_step`): 144 / 229 us; the env launch saved is worth less than the overlap lost.
     partition="cus": as "streams" but on CU-masked streams whose shares follow each layout's policy work
-        (`oc_cu_partition_create`).  Measured SLOWER (423 us): the masks do what they say (k bits -> k CUs, linear throughput,
+        (`oc_cu_partition_create`).  Measured SLOWER (328 us): the masks do what they say (k bits -> k CUs, linear throughput,
         profiles/r02_probe_cu_mask.log; two isolated launches side by side on half-device streams take 49.6 us against 91 us in a
         row), but these policy launches already scale with the CUs they get, so a fixed split only adds fragmentation.
-    Results are identical in all three modes.
+    partition="one_launch": everything on the current stream with TWO launches per joint step -- one policy launch over all
+        engines' rows (`oc_policy_forward_multi`: one tile table balanced by block cost; per-layout launches cannot share a CU,
+        so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape 96 us
+        per joint step, 155 us with critics; config 5's 220 us.
+    Results are identical in all modes.
 
     nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
     critic_nets[i][side][g] as in FusedPairedRollout (or None)."""
 
     def __init__(self, group: EngineGroup, nets, threads, n_conventions: int, critic_nets=None, deterministic: bool = False, seed: int = 0,
-                 partition="streams"):
+                 partition="auto"):
         from .fused_policy import TILE_ACT, PolicyPlan, _shape
         from .policy import segment_policy_indices
         from .sharding import pairing_segments
@@ -163,9 +168,19 @@ class GroupPairedRollout:
         self._cus = (ctypes.c_int32 * n_eng)()
         if partition is True:
             partition = "cus"
-        if partition not in (False, None, "streams", "cus"):
-            raise ValueError("partition must be False, 'streams' (one ordinary stream per engine) or 'cus' (CU-masked streams)")
-        self.partition = partition if (partition and n_eng > 1) else False
+        if partition == "auto":
+            # one launch over all grids wins while a pairing segment is worth a good many 32-row blocks (config 3: 17 per segment,
+            # 96 / 155 us per joint step against 130 / 180 on five streams); with short segments (config 5: 5 blocks each) a
+            # workgroup's stretch is mostly network switches and half-empty rounds of its four wavefronts (220 against 208 us)
+            partition = "one_launch" if min(self.threads) >= 8 * 32 else "streams"
+        if partition not in (False, None, "streams", "cus", "one_launch"):
+            raise ValueError("partition must be 'auto', False, 'streams' (one ordinary stream per engine), 'cus' (CU-masked streams) or 'one_launch'")
+        self.partition = partition if (partition and (n_eng > 1 or partition == "one_launch")) else False
+        self._one_launch = self.partition == "one_launch"
+        if self._one_launch:
+            from .fused_policy import MultiPolicyPlan
+            self.partition = False                                        # stream handling as the single-stream mode
+            self.multi_plan = MultiPolicyPlan(self.nets, [2 * e.num_kitchens for e in group.engines], rows_all)
         self._partitioned = self.partition == "cus"                       # CU budgets apply
         self._side_streams = bool(self.partition)
         self._torch_streams = None
@@ -201,6 +216,13 @@ class GroupPairedRollout:
             s.d_packed, s.n_nets, s.d_tiles, s.n_tiles = p(nt.image), nt.n_nets, p(plan.tiles), plan.n_tiles
             s.d_obs, s.d_actions, s.d_action_logp, s.d_values = p(obs[i]), p(actions[i]), p(logp[i]), p(values[i])
             s.d_reward, s.d_done = p(reward[i]), p(done[i])
+        if self._one_launch:
+            native.check(self._L.oc_group_policy_rollout_multi(
+                self.group._handle, slots, _vp(self.multi_plan.tiles.data_ptr()), self.multi_plan.n_tiles, self.multi_plan.tiles_per_workgroup, int(T),
+                1 if in_place else 0,
+                0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
+            self.steps_done += int(T)
+            return
         native.check(self._L.oc_group_policy_rollout(
             self.group._handle, slots, self._streams if self._side_streams else None, self._cus if self._partitioned else None, int(T),
             1 if in_place else 0, 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))

@@ -37,7 +37,7 @@ SYMBOLS = [
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
     "oc_import_states", "oc_import_states_checked", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_set_cu_budget",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
-    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_cus", "oc_policy_uniform", "oc_policy_rollout",
+    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_cus", "oc_policy_forward_multi", "oc_policy_plan_tiles_multi", "oc_group_policy_rollout_multi", "oc_policy_uniform", "oc_policy_rollout",
     "oc_cu_partition_create", "oc_cu_partition_destroy", "oc_group_policy_rollout",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
@@ -54,6 +54,13 @@ class OcGroupPolicySlot(ctypes.Structure):
     _fields_ = [("shape", ctypes.POINTER(OcPolicyShape)), ("d_packed", ctypes.c_void_p), ("n_nets", ctypes.c_int32),
                 ("d_tiles", ctypes.c_void_p), ("n_tiles", ctypes.c_int32), ("d_obs", ctypes.c_void_p), ("d_actions", ctypes.c_void_p),
                 ("d_action_logp", ctypes.c_void_p), ("d_values", ctypes.c_void_p), ("d_reward", ctypes.c_void_p), ("d_done", ctypes.c_void_p)]
+
+
+class OcPolicyMultiSlot(ctypes.Structure):
+    """struct oc_policy_multi_slot"""
+    _fields_ = [("shape", ctypes.POINTER(OcPolicyShape)), ("d_packed", ctypes.c_void_p), ("n_nets", ctypes.c_int32),
+                ("d_obs", ctypes.c_void_p), ("n_rows", ctypes.c_int64), ("d_raw", ctypes.c_void_p), ("d_actions", ctypes.c_void_p),
+                ("d_action_logp", ctypes.c_void_p), ("d_logp", ctypes.c_void_p), ("d_row_select", ctypes.c_void_p), ("seed", ctypes.c_uint32)]
 
 
 class OcLayoutParams(ctypes.Structure):
@@ -165,6 +172,10 @@ def lib():
     L.oc_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
     L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
                                           u32, u32, vp]
+    L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i64, i32, i32, u32, u32, vp]
+    L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, u32, vp, vp]
+    L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32)]
+    L.oc_policy_plan_tiles_multi.restype = i64
     L.oc_policy_uniform.argtypes = [u32, u32, u32, u32]
     L.oc_policy_uniform.restype = ctypes.c_float
     L.oc_last_error.argtypes = []

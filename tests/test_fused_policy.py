@@ -241,6 +241,58 @@ def test_kernel_other_grids_vs_oracle(W, H):
 
 
 @pytest.mark.gpu
+def test_multi_grid_launch_equals_per_grid_launches():
+    """oc_policy_forward_multi: three grids (6, 21 and 9 conv positions), actors and critics, ragged segments, ONE launch whose tile
+    table is balanced by block cost -- every output identical to the three per-grid launches with the same seeds and counter."""
+    from diverse_conventions_amd.fused_policy import MultiPolicyPlan, tile_slot
+    rng = np.random.default_rng(31)
+    grids, rows = [(5, 4), (9, 5), (5, 5)], [1000, 333, 2049]
+    nets, segs, obs = [], [], []
+    for (W, H), n in zip(grids, rows):
+        actors = [random_net(W, H, 6, ACTOR_HEAD, 100 + W * H + i) for i in range(2)]
+        critics = [random_net(W, H, 1, CRITIC_HEAD, 200 + W * H)]
+        nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=critics))
+        cut = n // 3
+        segs.append([(0, cut, 0, TILE_ACT), (cut, n - cut, 1, TILE_ACT), (0, n, 2, 0)])
+        obs.append(torch.from_numpy(((rng.random((n, W, H, 20)) < 0.15) * rng.integers(1, 21, (n, W, H, 20))).astype(np.int8)).cuda())
+    seeds, counter = [11, 22, 33], 5
+    new = lambda n, w, dt, fill: torch.full((n, w) if w else (n,), fill, dtype=dt, device="cuda")
+    want = []
+    for i, n in enumerate(rows):
+        o = dict(raw=new(n, 0, torch.float32, float("nan")), actions=new(n, 0, torch.int32, -1), action_logp=new(n, 0, torch.float32, float("nan")),
+                 logp=new(n, 6, torch.float32, float("nan")))
+        PolicyPlan(nets[i], n, segs[i]).forward(obs[i], seed=seeds[i], counter=counter, **o)
+        want.append(o)
+    got = [dict(raw=new(n, 0, torch.float32, float("nan")), actions=new(n, 0, torch.int32, -1), action_logp=new(n, 0, torch.float32, float("nan")),
+                logp=new(n, 6, torch.float32, float("nan"))) for n in rows]
+    assert MultiPolicyPlan(nets, rows, segs, workgroups=64).tiles_per_workgroup == 1      # 9 segments on 64 workgroups: one tile each
+    mp = MultiPolicyPlan(nets, rows, segs, workgroups=7)                                  # fewer workgroups than segments: packed stretches
+    tl = mp.tiles.cpu().numpy().reshape(mp.workgroups, mp.tiles_per_workgroup, 4)
+    live = tl[:, :, 1] > 0
+    assert set((tl[:, :, 3][live] >> 16).tolist()) == {0, 1, 2} and tile_slot(2) == 2 << 16
+    # every workgroup carries (about) the same cost: blocks weighted by conv positions + 2.5
+    cost_of = np.array([(W - 2) * (H - 2) + 2.5 for W, H in grids])
+    load = ((tl[:, :, 1] + 31) // 32 * cost_of[tl[:, :, 3] >> 16] * live).sum(1)
+    assert load.max() - load.min() <= 2 * cost_of.max() and load.min() > 0
+    # and the tiles cover every segment exactly once
+    for i, sg in enumerate(segs):
+        for row0, cnt, net, flags in sg:
+            m = live & ((tl[:, :, 3] >> 16) == i) & (tl[:, :, 2] == net) & ((tl[:, :, 3] & 0xFFFF) == flags)
+            spans = sorted((int(r), int(c)) for r, c in zip(tl[:, :, 0][m], tl[:, :, 1][m]) if row0 <= r < row0 + cnt)
+            assert spans[0][0] == row0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == row0 + cnt
+    for plan in (mp, MultiPolicyPlan(nets, rows, segs)):                                  # packed, then one tile per workgroup
+        for g in got:
+            g["raw"].fill_(float("nan")); g["actions"].fill_(-1); g["action_logp"].fill_(float("nan")); g["logp"].fill_(float("nan"))
+        plan.forward(obs, raw=[g["raw"] for g in got], actions=[g["actions"] for g in got], action_logp=[g["action_logp"] for g in got],
+                     logp=[g["logp"] for g in got], seeds=seeds, counter=counter)
+        torch.cuda.synchronize()
+        for i in range(3):
+            for key in ("raw", "actions", "action_logp", "logp"):
+                assert torch.equal(got[i][key], want[i][key]), (i, key, plan.tiles_per_workgroup)
+            assert int((got[i]["actions"] < 0).sum()) == 0 and not bool(torch.isnan(got[i]["raw"]).any())
+
+
+@pytest.mark.gpu
 def test_device_packer_equals_host_packer():
     for (W, H, n_out, head) in [(5, 4, 6, ACTOR_HEAD), (9, 5, 1, CRITIC_HEAD)]:
         sd = random_net(W, H, n_out, head, 11)

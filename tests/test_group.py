@@ -255,11 +255,11 @@ def test_the_group_binding_shown_in_integration_md_runs(layout_params):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("partition", ["cus", "streams", False])
+@pytest.mark.parametrize("partition", ["cus", "streams", False, "one_launch"])
 @pytest.mark.parametrize("deterministic", [True, False])
 def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deterministic, layout_params):
     """Policies in the loop over three layouts: per joint step three policy launches side by side on CU-masked streams
-    (or all on the launch stream) and ONE env launch.  Every engine's collected trajectory -- actions, log-probs, values,
+    (or all on the launch stream, or ONE policy launch over the three grids: "one_launch") and ONE env launch.  Every engine's collected trajectory -- actions, log-probs, values,
     observations, rewards, dones -- must be exactly what its own FusedPairedRollout collects with the same seed, and the env
     oracle driven by the recorded actions must reproduce the observations."""
     from diverse_conventions_amd import (EngineGroup, FusedPairedRollout, GroupPairedRollout, OvercookedEngine, PackedNetworks,

@@ -171,9 +171,11 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"
     ro.step(20)
     sec = timed(lambda: ro.step(T))
     kitchens = sum(e.num_kitchens for e in engines)
-    out = {"what": f"config 3 shape with policies in the loop, {k + 1} conventions in {G} segments x 5 layouts: 5 policy launches "
-                   + {"cus": "+ env launches, every engine on its own CU-masked stream", "streams": "+ env launches, every engine on its own stream",
-                      False: "one after the other on one stream + ONE env launch"}[partition] + " per joint step"
+    out = {"what": f"config 3 shape with policies in the loop, {k + 1} conventions in {G} segments x 5 layouts: "
+                   + {"cus": "5 policy launches + env launches, every engine on its own CU-masked stream",
+                      "streams": "5 policy launches + env launches, every engine on its own stream",
+                      "one_launch": "ONE policy launch over the five grids + ONE env launch",
+                      False: "5 policy launches one after the other on one stream + ONE env launch"}[partition] + " per joint step"
                    + (" (actors + critics)" if critics else " (actors)"),
            "kitchens_total": kitchens, "us_per_joint_step": round(sec * 1e6 / T, 1), "agent_env_steps_per_s": round(2 * kitchens * T / sec),
            "cu_shares": ro.cu_shares}
@@ -185,13 +187,13 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"
 if __name__ == "__main__":
     if "--group-policies" in sys.argv:
         print(json.dumps(config3_policies(critics=False)), flush=True)
-        for mode in (False, "streams", "cus"):
+        for mode in (False, "streams", "cus", "one_launch"):
             print(json.dumps(config3_group_policies(critics=False, partition=mode)), flush=True)
         print(json.dumps(config3_policies(critics=True)), flush=True)
-        for mode in (False, "streams"):
+        for mode in (False, "streams", "one_launch"):
             print(json.dumps(config3_group_policies(critics=True, partition=mode)), flush=True)
-        print(json.dumps(config3_group_policies(k=31, critics=True, partition="streams")), flush=True)     # config 5's per-GPU shape
-        print(json.dumps(config3_group_policies(k=31, critics=True, partition=False)), flush=True)
+        for mode in ("streams", False, "one_launch"):                                                       # config 5's per-GPU shape
+            print(json.dumps(config3_group_policies(k=31, critics=True, partition=mode)), flush=True)
         sys.exit(0)
     if "--group" in sys.argv:
         print(json.dumps(config3()), flush=True)
