@@ -112,6 +112,26 @@ class PackedNetworks:
         return nets
 
 
+def merge_segments(segments):
+    """Row ranges of one network with the same flags that touch become one segment: the pairing layout puts the main policy on a
+    run of consecutive segments of each side (train/XD/xd_player.py:76-77,94), and a merged run has no ragged 32-row block and no
+    weight reload at every internal boundary (config 5: 130-kitchen segments are four full blocks and a fifth with two rows).
+    Segments keep the order in which their (network, flags) first appears."""
+    groups = {}
+    for row0, rows, net, flags in (tuple(int(v) for v in s) for s in segments):
+        groups.setdefault((net, flags), []).append((row0, rows))
+    out = []
+    for (net, flags), spans in groups.items():
+        merged = []
+        for row0, rows in sorted(spans):
+            if merged and merged[-1][0] + merged[-1][1] == row0:
+                merged[-1] = (merged[-1][0], merged[-1][1] + rows)
+            else:
+                merged.append((row0, rows))
+        out += [(row0, rows, net, flags) for row0, rows in merged]
+    return out
+
+
 def plan_tiles(segments, rows_per_tile):
     """segments: iterable of (row0, rows, net, flags) -> int32 [n_tiles, 4] host tensor (oc_policy_plan_tiles)."""
     seg = np.asarray(list(segments), dtype=np.int64).reshape(-1, 4)
@@ -141,6 +161,7 @@ class PolicyPlan:
         for row0, rows, net, _ in segments:
             if row0 < 0 or rows < 0 or row0 + rows > self.n_rows or not 0 <= net < nets.n_nets:
                 raise ValueError(f"segment ({row0}, {rows}, net {net}) outside {self.n_rows} rows / {nets.n_nets} networks")
+        segments = merge_segments(segments)
         if rows_per_tile is None:
             # balanced plan: one tile per CU, pieces of one segment (= one network) each
             rows_per_tile = -torch.cuda.get_device_properties(nets.device).multi_processor_count
@@ -197,7 +218,7 @@ class MultiPolicyPlan:
             raise ValueError("all grids' networks must live on one device and use the same number of conv digits")
         rows = []
         for i, (nt, n, segs) in enumerate(zip(self.nets, self.n_rows, segments)):
-            for row0, cnt, net, flags in segs:
+            for row0, cnt, net, flags in merge_segments(segs):
                 if row0 < 0 or cnt < 0 or row0 + cnt > n or not 0 <= net < nt.n_nets:
                     raise ValueError(f"grid {i}: segment ({row0}, {cnt}, net {net}) outside {n} rows / {nt.n_nets} networks")
                 rows.append((int(row0), int(cnt), int(net), int(flags), i))

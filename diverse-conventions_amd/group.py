@@ -119,8 +119,8 @@ class GroupPairedRollout:
     partition="auto" (default): "one_launch" when every pairing segment holds at least 256 kitchens, else "streams".
     partition="streams": every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
         own stream, side by side with the others, no synchronisation between engines: one fork, one join per call.
-        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 130 us per joint step, 180 us with critics; config 5's
-        (32 conventions, 63 segments, critics): 208 us (profiles/r02_bench_group_policies.log).
+        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 128 us per joint step, 176 us with critics; config 5's
+        (32 conventions, 63 segments, critics): 202 us (profiles/r02_bench_group_policies.log).
     partition=False: everything on the current stream -- the policy launches one after the other, then ONE env launch for all
         engines (`oc_group_step`): 144 / 229 us; the env launch saved is worth less than the overlap lost.
     partition="cus": as "streams" but on CU-masked streams whose shares follow each layout's policy work
@@ -129,8 +129,8 @@ class GroupPairedRollout:
         row), but these policy launches already scale with the CUs they get, so a fixed split only adds fragmentation.
     partition="one_launch": everything on the current stream with TWO launches per joint step -- one policy launch over all
         engines' rows (`oc_policy_forward_multi`: one tile table balanced by block cost; per-layout launches cannot share a CU,
-        so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape 96 us
-        per joint step, 155 us with critics; config 5's 220 us.
+        so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape 95 us
+        per joint step, 154 us with critics; config 5's 215 us.
     Results are identical in all modes.
 
     nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
@@ -170,8 +170,8 @@ class GroupPairedRollout:
             partition = "cus"
         if partition == "auto":
             # one launch over all grids wins while a pairing segment is worth a good many 32-row blocks (config 3: 17 per segment,
-            # 96 / 155 us per joint step against 130 / 180 on five streams); with short segments (config 5: 5 blocks each) a
-            # workgroup's stretch is mostly network switches and half-empty rounds of its four wavefronts (220 against 208 us)
+            # 95 / 154 us per joint step against 128 / 176 on five streams); with short segments (config 5: 5 blocks each) a
+            # workgroup's stretch is mostly network switches and half-empty rounds of its four wavefronts (215 against 202 us)
             partition = "one_launch" if min(self.threads) >= 8 * 32 else "streams"
         if partition not in (False, None, "streams", "cus", "one_launch"):
             raise ValueError("partition must be 'auto', False, 'streams' (one ordinary stream per engine), 'cus' (CU-masked streams) or 'one_launch'")
