@@ -124,6 +124,63 @@ def test_abi_argument_checks_and_tile_plan():
         plan_tiles([(0, 10, 0, 0)], 100)                     # not a multiple of 32
 
 
+def _plan_multi(segs, costs, workgroups):
+    import ctypes
+    seg = np.asarray(segs, dtype=np.int64).reshape(-1, 5)
+    cols = [np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1])] + [np.ascontiguousarray(seg[:, j].astype(np.int32)) for j in (2, 3, 4)]
+    cost = np.asarray(costs, dtype=np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    per = ctypes.c_int32(0)
+    L = native.lib()
+    n = L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, None, 0, ctypes.byref(per))
+    if n < 0:
+        return int(n), None, 0
+    tiles = np.zeros((int(n), 4), dtype=np.int32)
+    assert L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, p(tiles), int(n), ctypes.byref(per)) == n
+    return int(n), tiles.reshape(workgroups if per.value > 1 or n == workgroups else -1, -1, 4), per.value
+
+
+def test_multi_grid_tile_plan_balances_cost_and_covers_every_row():
+    """oc_policy_plan_tiles_multi (host only): with many short segments (config 5's shape: 63 segments of 130 rows per side, an actor and
+    a critic each, five grids of different block cost) every workgroup gets an equal share of the cost and every row of every
+    segment is covered exactly once; with two workgroups per segment or more the plan is one tile per workgroup."""
+    costs = [8.5, 23.5, 11.5, 11.5, 20.5]
+    segs = []
+    for slot in range(5):
+        for side in range(2):
+            for g in range(63):
+                segs.append((side * 8190 + g * 130, 130, g % 33, TILE_ACT, slot))
+                segs.append((side * 8190 + g * 130, 130, 33 + g, 0, slot))
+    n, tiles, per = _plan_multi(segs, costs, 256)
+    assert per > 1 and n == 256 * per and tiles.shape == (256, per, 4)
+    live = tiles[:, :, 1] > 0
+    load = ((tiles[:, :, 1] + 31) // 32 * np.asarray(costs)[tiles[:, :, 3] >> 16] * live).sum(1)
+    assert load.max() - load.min() <= 2 * max(costs) and load.min() > 0.9 * load.mean()
+    covered = {}
+    for r0, cnt, net, fl in tiles[live]:
+        key = (int(fl) >> 16, int(net), int(fl) & 0xFFFF)
+        covered.setdefault(key, []).append((int(r0), int(cnt)))
+    for r0, cnt, net, fl, slot in segs:
+        spans = sorted(sp for sp in covered[(slot, net, fl)] if r0 <= sp[0] < r0 + cnt)
+        assert spans[0][0] == r0 and spans[-1][0] + spans[-1][1] == r0 + cnt and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(sp[0] % 32 == r0 % 32 for sp in spans)                     # cuts fall on the segment's own 32-row blocks
+    # few long segments: one tile per workgroup, workgroups in proportion to cost
+    n2, tiles2, per2 = _plan_multi([(0, 8192, 0, TILE_ACT, 0), (0, 8192, 0, TILE_ACT, 1)], costs[:2], 256)
+    assert per2 == 1 and n2 <= 256
+    t2 = tiles2.reshape(-1, 4)
+    share = np.bincount(t2[:, 3] >> 16, minlength=2)
+    assert abs(share[1] / share[0] - 23.5 / 8.5) < 0.2
+    # argument errors are reported, not crashed on
+    assert _plan_multi([(0, 10, 0, 0, 5)], costs, 256)[0] < 0 and "slot" in native.lib().oc_last_error().decode()
+    assert _plan_multi([(0, 10, 0, 0, 0)], [0.0], 256)[0] < 0
+
+
+def test_merge_segments_joins_touching_ranges_of_one_network():
+    from diverse_conventions_amd.fused_policy import merge_segments
+    got = merge_segments([(0, 10, 0, 1), (0, 10, 5, 0), (10, 10, 0, 1), (10, 10, 6, 0), (20, 5, 1, 1), (40, 10, 0, 1), (30, 10, 0, 1)])
+    assert got == [(0, 20, 0, 1), (30, 20, 0, 1), (0, 10, 5, 0), (10, 10, 6, 0), (20, 5, 1, 1)]
+
+
 def test_recurrent_state_dicts_are_refused_before_any_gpu_work():
     import inspect
     from diverse_conventions_amd import fused_policy
