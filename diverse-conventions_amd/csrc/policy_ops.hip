@@ -62,6 +62,7 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 constexpr int kMaxOut = 8;
 
+constexpr int kWaveTileBlocks = 12;    // segments shorter than this (in 32-row blocks, on average) run as wave tiles (oc_policy_plan_tiles_multi)
 constexpr int kMaxSlots = 8;           // observation tensors (grids) one launch can serve: tile flags carry the slot index
 
 // One observation tensor with the networks that read it and the buffers they write (oc_policy_forward: one;
@@ -282,7 +283,11 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
 // MULTI: the tile table runs over several slots (grids); everything that depends on the grid is then re-derived per tile.
 // Such launches keep the conv digits in registers and fc1 in L2 (the LDS-resident tail -- biases, fc2, head -- has the same
 // layout for every grid), and map workgroup i to tile i.
-template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false>
+// TAIL_LDS = false ("wave tiles"): nothing of the network lives in LDS -- biases, fc2 and head fragments are read from L2 per
+// block like fc1 -- so a workgroup is ONE wavefront with its own network, four independent ones per CU.  For tables of short
+// segments (config 5: five 32-row blocks per segment and network), where a four-wavefront workgroup that must stay on one
+// network leaves 3 of 8 wavefront slots empty.
+template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false, bool TAIL_LDS = true>
 __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
@@ -322,13 +327,13 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     __amdgpu_buffer_rsrc_t w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.slot[0].packed), 0, 0, 0x00020000);
     const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
     const v4i *w1l = reinterpret_cast<const v4i *>(lds_tail + (L0.off_fc1 - wstart)) + lane;
-    const float *b1 = reinterpret_cast<const float *>(lds_tail + (L0.off_b1 - wstart)) + h * 16;
-    const v4i *w2 = reinterpret_cast<const v4i *>(lds_tail + (L0.off_fc2 - wstart)) + lane;
-    const float *b2 = reinterpret_cast<const float *>(lds_tail + (L0.off_b2 - wstart)) + h * 16;
+    const float *b1 = TAIL_LDS ? reinterpret_cast<const float *>(lds_tail + (L0.off_b1 - wstart)) + h * 16 : nullptr;
+    const v4i *w2 = TAIL_LDS ? reinterpret_cast<const v4i *>(lds_tail + (L0.off_fc2 - wstart)) + lane : nullptr;
+    const float *b2 = TAIL_LDS ? reinterpret_cast<const float *>(lds_tail + (L0.off_b2 - wstart)) + h * 16 : nullptr;
     // head: only the outputs a < 8 are stored, [piece][k-group][8 h + a]; the other rows of the A operand are zero registers
     const bool head_lane = col < 8;
-    const v4i *wh = reinterpret_cast<const v4i *>(lds_tail + (L0.off_head - wstart)) + (8 * h + (col & 7));
-    const float *bh = reinterpret_cast<const float *>(lds_tail + (L0.off_bh - wstart)) + h * 4;
+    const v4i *wh = TAIL_LDS ? reinterpret_cast<const v4i *>(lds_tail + (L0.off_head - wstart)) + (8 * h + (col & 7)) : nullptr;
+    const float *bh = TAIL_LDS ? reinterpret_cast<const float *>(lds_tail + (L0.off_bh - wstart)) + h * 4 : nullptr;
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     int colstep = H * OC_POLICY_C;
     int loaded_net = -1, loaded_slot = 0, n_out = 1;
@@ -441,6 +446,13 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             cbeta = *reinterpret_cast<const v16i *>(blob + S.L.off_conv_sb + 128 + h * 64);
         }
         w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(blob + S.L.off_fc1), 0, P * OC_POLICY_FC1_POS_BYTES, 0x00020000);
+        if (!TAIL_LDS) {                                              // the tail stays in global memory (L2): this network's sections
+            b1 = reinterpret_cast<const float *>(blob + S.L.off_b1) + h * 16;
+            w2 = reinterpret_cast<const v4i *>(blob + S.L.off_fc2) + lane;
+            b2 = reinterpret_cast<const float *>(blob + S.L.off_b2) + h * 16;
+            wh = reinterpret_cast<const v4i *>(blob + S.L.off_head) + (8 * h + (col & 7));
+            bh = reinterpret_cast<const float *>(blob + S.L.off_bh) + h * 4;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's share of the weight copy has landed
         __syncthreads();                                              // the network is in LDS
         loaded_net = net;
@@ -494,6 +506,13 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 for (int r = 0; r < 16; ++r) h1[m][r] = bq[m * 8 + (r >> 2)][r & 3];
         }
         if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
+        // wave tiles: the dense layers' biases come from L2 -- requested here, used after the position loop
+        v4f b2q[TAIL_LDS ? 1 : 8], bhq = {0.f, 0.f, 0.f, 0.f};
+        if (!TAIL_LDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b2q[TAIL_LDS ? 0 : i] = reinterpret_cast<const v4f *>(b2)[(i >> 2) * 8 + (i & 3)];
+            bhq = *reinterpret_cast<const v4f *>(bh);
+        }
         // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
         auto make_operand = [&](v4i (&dst)[3][2], int j) {            // pair j = accumulator registers 2j, 2j + 1
             int hi, mid, lo;
@@ -571,8 +590,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h2[m][r] = bq[m * 8 + (r >> 2)][r & 3];
-            const v4f bhv = *reinterpret_cast<const v4f *>(bh);
+                for (int r = 0; r < 16; ++r) h2[m][r] = TAIL_LDS ? bq[m * 8 + (r >> 2)][r & 3] : b2q[TAIL_LDS ? 0 : m * 4 + (r >> 2)][r & 3];
+            const v4f bhv = TAIL_LDS ? *reinterpret_cast<const v4f *>(bh) : bhq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { out[r] = r < 4 ? bhv[r] : 0.f; out2[r] = 0.f; }
         }
@@ -595,24 +614,40 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 dst[0][j] = hi; dst[1][j] = mid; dst[2][j] = lo;
             }
         };
+        // weight fragments: from LDS one k-group ahead; from L2 (wave tiles) all four k-groups at once, and the head's as well,
+        // half-way through fc2 -- twelve MFMAs (0.2 us) do not cover an L2 round trip
+        constexpr int WB = TAIL_LDS ? 2 : 4;                          // fragment buffers
+        v4i whr[WB][3];
+        auto load_wh = [&](int kg) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) whr[kg % WB][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
+        };
         {
             v4i hb[2][3];                                             // [parity of kg][piece]
-            v4i w2r[2][3][2];                                         // [parity of kg][piece][out half]
+            v4i w2r[WB][3][2];                                        // [kg % WB][piece][out half]
             auto load_w2 = [&](int kg) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int mo = 0; mo < 2; ++mo) w2r[kg & 1][q][mo] = w2[((q * 4 + kg) * 2 + mo) * 64];
+                    for (int mo = 0; mo < 2; ++mo) w2r[kg % WB][q][mo] = w2[((q * 4 + kg) * 2 + mo) * 64];
             };
             load_w2(0);
+            if (!TAIL_LDS) {
+#pragma unroll
+                for (int kg = 1; kg < 4; ++kg) load_w2(kg);
+            }
             split_group(h1[0], 0, hb[0]);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
-                if (kg + 1 < 4) load_w2(kg + 1);
+                if (TAIL_LDS && kg + 1 < 4) load_w2(kg + 1);
+                if (!TAIL_LDS && kg == 2) {                           // (the first two k-groups' fragments have been consumed)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) load_wh(k2);
+                }
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    h2[0] = mfma_bf16(w2r[kg & 1][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
-                    h2[1] = mfma_bf16(w2r[kg & 1][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
+                    h2[0] = mfma_bf16(w2r[kg % WB][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
+                    h2[1] = mfma_bf16(w2r[kg % WB][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
                 }
                 if (kg + 1 < 4) split_group(h1[(kg + 1) >> 1], (kg + 1) & 1, hb[(kg + 1) & 1]);
             }
@@ -621,20 +656,16 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (traced2) stamp(a, wave, lane, 28);
         // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; two accumulators so consecutive MFMAs do not wait for each other ----
         {
-            v4i gb[2][3], whr[2][3];
-            auto load_wh = [&](int kg) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) whr[kg & 1][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
-            };
-            load_wh(0);
+            v4i gb[2][3];
+            if (TAIL_LDS) load_wh(0);
             split_group(h2[0], 0, gb[0]);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
-                if (kg + 1 < 4) load_wh(kg + 1);
+                if (TAIL_LDS && kg + 1 < 4) load_wh(kg + 1);
 #pragma unroll
                 for (int t = 0; t < 6; t += 2) {
-                    out = mfma_bf16(whr[kg & 1][kTermW[t]], gb[kg & 1][kTermX[t]], out);
-                    out2 = mfma_bf16(whr[kg & 1][kTermW[t + 1]], gb[kg & 1][kTermX[t + 1]], out2);
+                    out = mfma_bf16(whr[kg % WB][kTermW[t]], gb[kg & 1][kTermX[t]], out);
+                    out2 = mfma_bf16(whr[kg % WB][kTermW[t + 1]], gb[kg & 1][kTermX[t + 1]], out2);
                 }
                 if (kg + 1 < 4) split_group(h2[(kg + 1) >> 1], (kg + 1) & 1, gb[(kg + 1) & 1]);
             }
@@ -845,17 +876,29 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
 
 int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
                                    const int32_t *seg_slot, const float *slot_cost, int32_t n_slots, int32_t n_segs, int32_t workgroups,
-                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup) {
-    if (!seg_row0 || !seg_rows || !seg_net || !seg_slot || !slot_cost || !tiles_per_workgroup || n_slots < 1 || n_slots > kMaxSlots ||
-        workgroups < 1 || n_segs < 0)
+                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup, int32_t *waves_per_workgroup) {
+    if (!seg_row0 || !seg_rows || !seg_net || !seg_slot || !slot_cost || !tiles_per_workgroup || !waves_per_workgroup || n_slots < 1 ||
+        n_slots > kMaxSlots || workgroups < 1 || n_segs < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: NULL pointer, 1..%d slots with their costs, workgroups >= 1", kMaxSlots);
     // At least two workgroups per segment: the single-grid plan with costs -- workgroups shared out over the segments in proportion
     // to their work, one tile each, no workgroup ever changes network (config 3's actors: 96 us per joint step against 103 packed).
     // With fewer, whole workgroups per segment no longer balance (235 segments on 256 workgroups: 196 us against 155 packed).
+    *waves_per_workgroup = 4;
     {
         int32_t live = 0;
-        for (int32_t g = 0; g < n_segs; ++g) live += seg_rows[g] > 0 ? 1 : 0;
-        if (2 * live <= workgroups) {
+        int64_t all_blocks = 0;
+        for (int32_t g = 0; g < n_segs; ++g) {
+            live += seg_rows[g] > 0 ? 1 : 0;
+            all_blocks += seg_rows[g] > 0 ? (seg_rows[g] + kRowsPerBlock - 1) / kRowsPerBlock : 0;
+        }
+        // Short segments (fewer than kWaveTileBlocks 32-row blocks each, on average): wave tiles -- four one-wavefront workgroups
+        // per CU, each with its own network in L2 / registers, planned as 4 x workgroups packed stretches.
+        const char *const env_wt = getenv("OC_POLICY_WAVE_TILES");   // diagnostics: "0" never, "1" always
+        const bool wave_tiles = env_wt && env_wt[0] ? env_wt[0] != '0' : (live > 0 && all_blocks < static_cast<int64_t>(kWaveTileBlocks) * live);
+        if (wave_tiles) {
+            *waves_per_workgroup = 1;
+            workgroups *= 4;
+        } else if (2 * live <= workgroups) {
             *tiles_per_workgroup = 1;
             return plan_tiles_impl("oc_policy_plan_tiles_multi", seg_row0, seg_rows, seg_net, seg_flags, seg_slot, slot_cost, n_slots, n_segs,
                                    -workgroups, host_tiles, capacity);
@@ -950,7 +993,7 @@ int fill_slot(PolicySlot &t, const oc_policy_shape *shape, const void *d_packed,
 int staging_bytes(int RB) { return (kRowsPerBlock * RB + 16 + 1023) / 1024 * 1024; }   // whole 1 KB LDS-DMA instructions (stage_rows)
 
 // Pick the LDS plan and launch.  `multi`: the tile table runs over a.n_slots grids.
-int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipStream_t stream) {
+int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipStream_t stream, bool wave_tiles = false) {
     const PolicySlot &s0 = a.slot[0];
     a.trace = g_trace;
     a.lds_wave_bytes = 0;
@@ -985,6 +1028,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
         if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
     a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
+    if (wave_tiles) { waves = 1; a.lds_weight_bytes = 0; }           // one-wavefront workgroups, the whole network in L2 / registers
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
     const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
     if (lds > static_cast<size_t>(kLds))
@@ -997,15 +1041,17 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
         {{oc_policy_kernel<4, false, false>, oc_policy_kernel<4, false, true>}, {oc_policy_kernel<4, true, false>, oc_policy_kernel<4, true, true>}}};
     static const kernel_t kernels_multi[4] = {oc_policy_kernel<1, false, false, true>, oc_policy_kernel<2, false, false, true>,
                                               oc_policy_kernel<3, false, false, true>, oc_policy_kernel<4, false, false, true>};
-    const kernel_t kernel = multi ? kernels_multi[digits - 1] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    static const kernel_t kernels_wave[4] = {oc_policy_kernel<1, false, false, true, false>, oc_policy_kernel<2, false, false, true, false>,
+                                             oc_policy_kernel<3, false, false, true, false>, oc_policy_kernel<4, false, false, true, false>};
+    const kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2][2] = {};                   // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][multi ? 1 : 0];
+    static size_t lds_granted[64][4][2][2][3] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -1062,7 +1108,7 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
 }
 
 int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                            int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream) {
+                            int32_t waves_per_workgroup, int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream) {
     if (!slots || n_slots < 1 || n_slots > kMaxSlots)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: 1..%d slots", kMaxSlots);
     if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15) || tiles_per_workgroup < 1 || n_tiles % tiles_per_workgroup)
@@ -1086,7 +1132,9 @@ int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, 
     a.n_tiles = n_tiles;
     a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
     a.tile_per_wg = tiles_per_workgroup;
-    return launch_policy(a, slots[0].shape->digits, true, 0, static_cast<hipStream_t>(stream));
+    if (waves_per_workgroup != 1 && waves_per_workgroup != 4)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_multi: waves_per_workgroup is 4, or 1 for wave tiles (as oc_policy_plan_tiles_multi returned it)");
+    return launch_policy(a, slots[0].shape->digits, true, 0, static_cast<hipStream_t>(stream), waves_per_workgroup == 1);
 }
 
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
@@ -1264,7 +1312,7 @@ int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void
 }
 
 int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                                  int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
+                                  int32_t waves_per_workgroup, int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
     const int n = oc_group_size(g);
     if (n < 1 || n > kMaxSlots || !slots || !d_tiles || T < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: NULL group / slots / tiles, negative T or more than %d engines", kMaxSlots);
@@ -1302,7 +1350,7 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
             rew[i] = s.d_reward + k * rows[i];
             done[i] = s.d_done + k * kitchens[i];
         }
-        if (int rc = oc_policy_forward_multi(ms.data(), n, d_tiles, n_tiles, tiles_per_workgroup, sample_mode, counter0 + static_cast<uint32_t>(t), nullptr, stream)) return rc;
+        if (int rc = oc_policy_forward_multi(ms.data(), n, d_tiles, n_tiles, tiles_per_workgroup, waves_per_workgroup, sample_mode, counter0 + static_cast<uint32_t>(t), nullptr, stream)) return rc;
         if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream)) return rc;
     }
     return OC_OK;

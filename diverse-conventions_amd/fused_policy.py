@@ -232,16 +232,16 @@ class MultiPolicyPlan:
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         L = native.lib()
         args = [p(c) for c in cols] + [p(cost), len(self.nets), len(seg), self.workgroups]
-        per = ctypes.c_int32(0)
-        n = L.oc_policy_plan_tiles_multi(*args, None, 0, ctypes.byref(per))
+        per, waves = ctypes.c_int32(0), ctypes.c_int32(0)
+        n = L.oc_policy_plan_tiles_multi(*args, None, 0, ctypes.byref(per), ctypes.byref(waves))
         if n < 0:
             native.check(int(n))
         tiles = np.zeros((max(int(n), 1), 4), dtype=np.int32)
-        n2 = L.oc_policy_plan_tiles_multi(*args, p(tiles), int(n), ctypes.byref(per))
+        n2 = L.oc_policy_plan_tiles_multi(*args, p(tiles), int(n), ctypes.byref(per), ctypes.byref(waves))
         if n2 < 0:
             native.check(int(n2))
         self.tiles = torch.from_numpy(tiles[:int(n)]).to(dev)
-        self.n_tiles, self.tiles_per_workgroup = int(n), int(per.value)
+        self.n_tiles, self.tiles_per_workgroup, self.waves_per_workgroup = int(n), int(per.value), int(waves.value)
         self.counter = 0
         self._shapes = [_shape(nt.W, nt.H, 6, nt.digits) for nt in self.nets]
 
@@ -270,7 +270,7 @@ class MultiPolicyPlan:
         if counter is None:
             counter, self.counter = self.counter, self.counter + 1
         dev = self.nets[0].device
-        native.check(native.lib().oc_policy_forward_multi(slots, k, _ptr(self.tiles), self.n_tiles, self.tiles_per_workgroup,
+        native.check(native.lib().oc_policy_forward_multi(slots, k, _ptr(self.tiles), self.n_tiles, self.tiles_per_workgroup, self.waves_per_workgroup,
                                                           0 if deterministic else 1, int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(dev)))
 
 

@@ -116,7 +116,7 @@ class GroupPairedRollout:
     this as five simulators and 5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26,
     train/XD/xd_player.py:190-207).  Kitchens of different engines never interact, so the engines need not march in step:
 
-    partition="auto" (default): "one_launch" when every pairing segment holds at least 256 kitchens, else "streams".
+    partition="auto" (default): "one_launch".
     partition="streams": every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
         own stream, side by side with the others, no synchronisation between engines: one fork, one join per call.
         Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 128 us per joint step, 176 us with critics; config 5's
@@ -130,7 +130,8 @@ class GroupPairedRollout:
     partition="one_launch": everything on the current stream with TWO launches per joint step -- one policy launch over all
         engines' rows (`oc_policy_forward_multi`: one tile table balanced by block cost; per-layout launches cannot share a CU,
         so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape 95 us
-        per joint step, 154 us with critics; config 5's 215 us.
+        per joint step, 155 us with critics; config 5's 191 us (its 130-kitchen segments run as "wave tiles": one-wavefront
+        workgroups that keep their whole network in L2 / registers, four different networks per CU).
     Results are identical in all modes.
 
     nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
@@ -169,10 +170,9 @@ class GroupPairedRollout:
         if partition is True:
             partition = "cus"
         if partition == "auto":
-            # one launch over all grids wins while a pairing segment is worth a good many 32-row blocks (config 3: 17 per segment,
-            # 95 / 154 us per joint step against 128 / 176 on five streams); with short segments (config 5: 5 blocks each) a
-            # workgroup's stretch is mostly network switches and half-empty rounds of its four wavefronts (215 against 202 us)
-            partition = "one_launch" if min(self.threads) >= 8 * 32 else "streams"
+            # one policy launch over all grids + one env launch: 95 / 155 us per joint step against 128 / 176 on five streams
+            # (config 3's shape), 191 against 202 us with config 5's short segments, which the planner runs as wave tiles
+            partition = "one_launch"
         if partition not in (False, None, "streams", "cus", "one_launch"):
             raise ValueError("partition must be 'auto', False, 'streams' (one ordinary stream per engine), 'cus' (CU-masked streams) or 'one_launch'")
         self.partition = partition if (partition and (n_eng > 1 or partition == "one_launch")) else False
@@ -218,7 +218,8 @@ class GroupPairedRollout:
             s.d_reward, s.d_done = p(reward[i]), p(done[i])
         if self._one_launch:
             native.check(self._L.oc_group_policy_rollout_multi(
-                self.group._handle, slots, _vp(self.multi_plan.tiles.data_ptr()), self.multi_plan.n_tiles, self.multi_plan.tiles_per_workgroup, int(T),
+                self.group._handle, slots, _vp(self.multi_plan.tiles.data_ptr()), self.multi_plan.n_tiles, self.multi_plan.tiles_per_workgroup,
+                self.multi_plan.waves_per_workgroup, int(T),
                 1 if in_place else 0,
                 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
             self.steps_done += int(T)

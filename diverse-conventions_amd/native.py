@@ -172,9 +172,9 @@ def lib():
     L.oc_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
     L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
                                           u32, u32, vp]
-    L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i64, i32, i32, u32, u32, vp]
-    L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, u32, vp, vp]
-    L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32)]
+    L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i32, i64, i32, i32, u32, u32, vp]
+    L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, i32, u32, vp, vp]
+    L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.oc_policy_plan_tiles_multi.restype = i64
     L.oc_policy_uniform.argtypes = [u32, u32, u32, u32]
     L.oc_policy_uniform.restype = ctypes.c_float

@@ -309,7 +309,10 @@ int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, in
  * segments at the share boundaries: host_tiles then holds *tiles_per_workgroup entries per workgroup (empty ones as padding),
  * workgroups * *tiles_per_workgroup in all (the return value; host_tiles may be NULL to ask for it).  Five per-layout
  * launches cannot share a CU (each fills its registers and LDS), so at 8192 kitchens per layout they leave half the SIMDs
- * without a block; one balanced table does not.  All slots' networks must use the same number of conv digits; at most 8 slots. */
+ * without a block; one balanced table does not.  All slots' networks must use the same number of conv digits; at most 8 slots.
+ * *waves_per_workgroup comes back 4, or 1 for tables of short segments (fewer than 12 blocks each on average: "wave tiles" -- the
+ * table is then planned for 4 x workgroups one-wavefront workgroups that keep their whole network in L2 / registers, so four
+ * different networks run on a CU side by side); pass both numbers on to oc_policy_forward_multi. */
 #define OC_POLICY_TILE_SLOT(i) (((i) & 7) << 16)
 typedef struct {
     const oc_policy_shape *shape;
@@ -326,9 +329,9 @@ typedef struct {
 } oc_policy_multi_slot;
 int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
                                    const int32_t *seg_slot, const float *slot_cost, int32_t n_slots, int32_t n_segs, int32_t workgroups,
-                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup);
+                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup, int32_t *waves_per_workgroup);
 int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                            int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream);
+                            int32_t waves_per_workgroup, int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream);
 /* n HIP streams restricted to disjoint sets of the device's CUs, stream i getting about shares[i] / sum(shares) of them (at
  * least one; every set spread over the whole CU index range).  k mask bits give k CUs and proportional throughput
  * (tools/probes/cu_mask.hip); two isolated policy launches of 8184 asymmetric_advantages kitchens take 49.6 us together on two
@@ -367,7 +370,7 @@ int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void
  * (d_tiles from oc_policy_plan_tiles_multi, slot i = engine i; the slots' own d_tiles are ignored) and one oc_group_step.
  * Same seeds and counters as oc_group_policy_rollout: identical results. */
 int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                                  int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
+                                  int32_t waves_per_workgroup, int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
 /* T rollout steps with the policies in the loop, enqueued from C (no host work between launches): per step one
  * oc_policy_forward over the 2N rows of the engine's observation (tiles address rows player * N + kitchen; critic
  * tiles write d_values) and one oc_step.  What XDPlayer.next_step does per step through 2(2k+1) get_actions calls

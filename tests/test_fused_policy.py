@@ -130,14 +130,16 @@ def _plan_multi(segs, costs, workgroups):
     cols = [np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1])] + [np.ascontiguousarray(seg[:, j].astype(np.int32)) for j in (2, 3, 4)]
     cost = np.asarray(costs, dtype=np.float32)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    per = ctypes.c_int32(0)
+    per, waves = ctypes.c_int32(0), ctypes.c_int32(0)
     L = native.lib()
-    n = L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, None, 0, ctypes.byref(per))
+    n = L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, None, 0, ctypes.byref(per), ctypes.byref(waves))
     if n < 0:
         return int(n), None, 0
     tiles = np.zeros((int(n), 4), dtype=np.int32)
-    assert L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, p(tiles), int(n), ctypes.byref(per)) == n
-    return int(n), tiles.reshape(workgroups if per.value > 1 or n == workgroups else -1, -1, 4), per.value
+    assert L.oc_policy_plan_tiles_multi(*[p(c) for c in cols], p(cost), len(costs), len(seg), workgroups, p(tiles), int(n), ctypes.byref(per),
+                                        ctypes.byref(waves)) == n
+    wgs = workgroups * (4 if waves.value == 1 else 1)
+    return int(n), tiles.reshape(wgs if per.value > 1 or n == wgs else -1, -1, 4), per.value
 
 
 def test_multi_grid_tile_plan_balances_cost_and_covers_every_row():
@@ -151,11 +153,11 @@ def test_multi_grid_tile_plan_balances_cost_and_covers_every_row():
             for g in range(63):
                 segs.append((side * 8190 + g * 130, 130, g % 33, TILE_ACT, slot))
                 segs.append((side * 8190 + g * 130, 130, 33 + g, 0, slot))
-    n, tiles, per = _plan_multi(segs, costs, 256)
-    assert per > 1 and n == 256 * per and tiles.shape == (256, per, 4)
+    n, tiles, per = _plan_multi(segs, costs, 256)                             # 5-block segments: planned as wave tiles, 4 x 256 stretches
+    assert per >= 1 and n == 1024 * per and tiles.shape == (1024, per, 4)
     live = tiles[:, :, 1] > 0
     load = ((tiles[:, :, 1] + 31) // 32 * np.asarray(costs)[tiles[:, :, 3] >> 16] * live).sum(1)
-    assert load.max() - load.min() <= 2 * max(costs) and load.min() > 0.9 * load.mean()
+    assert load.max() - load.min() <= 2 * max(costs) and load.min() > load.mean() - max(costs)
     covered = {}
     for r0, cnt, net, fl in tiles[live]:
         key = (int(fl) >> 16, int(net), int(fl) & 0xFFFF)
@@ -337,7 +339,14 @@ def test_multi_grid_launch_equals_per_grid_launches():
             m = live & ((tl[:, :, 3] >> 16) == i) & (tl[:, :, 2] == net) & ((tl[:, :, 3] & 0xFFFF) == flags)
             spans = sorted((int(r), int(c)) for r, c in zip(tl[:, :, 0][m], tl[:, :, 1][m]) if row0 <= r < row0 + cnt)
             assert spans[0][0] == row0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == row0 + cnt
-    for plan in (mp, MultiPolicyPlan(nets, rows, segs)):                                  # packed, then one tile per workgroup
+    os.environ["OC_POLICY_WAVE_TILES"] = "1"                                                # the planner reads it per call
+    try:
+        wave_plan = MultiPolicyPlan(nets, rows, segs)
+    finally:
+        del os.environ["OC_POLICY_WAVE_TILES"]
+    assert wave_plan.waves_per_workgroup == 1 and mp.waves_per_workgroup == 4
+    # packed stretches, one tile per workgroup, wave tiles (one-wavefront workgroups, the network in L2)
+    for plan in (mp, MultiPolicyPlan(nets, rows, segs), wave_plan):
         for g in got:
             g["raw"].fill_(float("nan")); g["actions"].fill_(-1); g["action_logp"].fill_(float("nan")); g["logp"].fill_(float("nan"))
         plan.forward(obs, raw=[g["raw"] for g in got], actions=[g["actions"] for g in got], action_logp=[g["action_logp"] for g in got],
