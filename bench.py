@@ -295,7 +295,10 @@ def main():
                     "unit": "agent-env steps/s",
                     "policy_kernel": {"kernel": "oc_policy_kernel<4 digits>", "us_per_launch": pol_us, "network_evaluations": rows,
                                       "useful_TFLOPs": rows * 2 * (P * 180 * 32 + P * 32 * 64 + 64 * 64 + 64 * 6) / pol_us * 1e-6,
-                                      "bound": "mfma", "issue_bound_us_at_2.4GHz": bound_us, "frac": bound_us / pol_us}}
+                                      "bound": "mfma", "issue_bound_us_at_2.4GHz": bound_us, "frac": bound_us / pol_us,
+                                      "note": "matrix cycles per 32 rows: 11 520 (i8 conv digits + bf16 piece products for the dense layers; 23 040 "
+                                              "with f32 MFMAs in round 1, when this launch took 77.7 us); the VALU work between the layers "
+                                              "(~1780 instructions per block) does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
           eng2.close()
       except Exception as exc:                             # noqa: BLE001
         policy = {"error": f"{type(exc).__name__}: {exc}"}
