@@ -55,7 +55,7 @@ extern "C" {
 #define OC_MAX_TILES 255
 #define OC_MAX_PLAYERS 4
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 3
+#define OC_ABI_VERSION 4
 
 typedef enum {
     OC_OK = 0,

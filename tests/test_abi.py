@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(native.SYMBOLS) == declared
     for name in declared:
         assert getattr(L, name) is not None, name
-    assert L.oc_abi_version() == 3
+    assert L.oc_abi_version() == 4
 
 
 def test_layout_struct_matches_header():
