@@ -112,4 +112,4 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
-    assert out[0] == "-2" and "players" in out[1] and out[2] == "3" and out[3] == "0"
+    assert out[0] == "-2" and "players" in out[1] and out[2] == "4" and out[3] == "0"
