@@ -833,6 +833,28 @@ int64_t plan_tiles_impl(const char *who, const int64_t *seg_row0, const int64_t 
             pieces[g] = blocks[g] == 0 ? 0 : std::max<int64_t>(1, std::min(blocks[g], total > 0 ? static_cast<int64_t>(wgs * (blocks[g] * cost[g]) / total) : 1));
             used += pieces[g];
         }
+        // A workgroup's wavefronts take its blocks round-robin, so what a piece costs is its number of ROUNDS: 17 blocks on 8
+        // wavefronts take as long as 24.  Try piece sizes that are whole rounds (multiples of 8 blocks: whole rounds for 4
+        // wavefronts too): the smallest such size whose pieces fit the workgroups, if it needs fewer rounds than the
+        // proportional split (15 segments of 4369 kitchens per side on 256 workgroups: 137-block segments got 8 pieces of
+        // 17-18 blocks, three rounds; nine pieces of 15-16 are two).
+        if (!seg_slot) {
+            int64_t worst_now = 0, all_blocks = 0;
+            for (int32_t g = 0; g < n_segs; ++g) {
+                if (pieces[g] > 0) worst_now = std::max(worst_now, (blocks[g] + pieces[g] - 1) / pieces[g]);
+                all_blocks += blocks[g];
+            }
+            for (int64_t size = std::max<int64_t>(8, (all_blocks / wgs + 7) / 8 * 8); size < worst_now; size += 8) {
+                int64_t need = 0;
+                for (int32_t g = 0; g < n_segs; ++g) need += (blocks[g] + size - 1) / size;
+                if (need > wgs) continue;
+                if ((size + 7) / 8 < (worst_now + 7) / 8) {
+                    used = 0;
+                    for (int32_t g = 0; g < n_segs; ++g) { pieces[g] = (blocks[g] + size - 1) / size; used += pieces[g]; }
+                }
+                break;
+            }
+        }
         for (; used < wgs; ++used) {
             int32_t best = -1;
             double worst = 0.0;                                       // only segments whose pieces exceed one block
