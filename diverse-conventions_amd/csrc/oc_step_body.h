@@ -354,6 +354,39 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 // ---- flush the staged tiles of both viewers: contiguous bytes in the output planes
                 const int gbytes = (min(ntiles - p0 * tpp, KP_gpasses(a) * tpp)) * kChannels;
                 const int64_t goff = plane_base + static_cast<int64_t>(p0) * tpp * kChannels;
+#if defined(OC_JIT) && ((defined(OC_FAST_FLUSH) && OC_FAST_FLUSH) || (!defined(OC_FAST_FLUSH) && OC_S <= 32))
+                // Specialised build, full flush group (every one but a ragged last): the chunk count is a constant, so all LDS
+                // reads of both viewers go out first (one latency instead of one per chunk and viewer in a dependent
+                // read / wait / store loop), then the stores, addressed as scalar base + lane offset + immediate.
+                // Measured per grid (profiles/r02_ab_geometry_flush.log, 65 536 kitchens): cramped_room 11.93 -> 11.90 us with 16
+                // kitchens per group and 11.98 -> 11.80 with 32; coordination_ring 13.88 -> 13.77; counter_circuit 20.00 -> 20.03;
+                // asymmetric_advantages 22.09 -> 22.76 (the 24 extra registers cost more there than the loop did): grids of at
+                // most 32 tiles only.
+                constexpr int kFullBytes = OC_GP * (OC_KPP > 0 ? OC_KPP * OC_S : kWave) * kChannels;
+                constexpr int kFullChunks = kFullBytes / 16, kIts = (kFullChunks + kWave - 1) / kWave;
+                if (VEC16 && kFullBytes % 16 == 0 && kIts <= 6 && gbytes == kFullBytes) {
+                    uint4 r[2][kIts];
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int i = 0; i < kIts; ++i)
+                            if ((i + 1) * kWave <= kFullChunks || lane + i * kWave < kFullChunks)
+                                r[v][i] = *reinterpret_cast<const uint4 *>(L.stage[v] + 4 * (lane + i * kWave));
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        int8_t *base = obs_t + v * a.obs_player_stride + goff;
+#pragma unroll
+                        for (int i = 0; i < kIts; ++i)
+                            if ((i + 1) * kWave <= kFullChunks || lane + i * kWave < kFullChunks) {
+                                if ((i & 3) == 0) store16_s<SM, 0>(base + (i >> 2) * 4096, lane * 16u, r[v][i]);
+                                else if ((i & 3) == 1) store16_s<SM, 1024>(base + (i >> 2) * 4096, lane * 16u, r[v][i]);
+                                else if ((i & 3) == 2) store16_s<SM, 2048>(base + (i >> 2) * 4096, lane * 16u, r[v][i]);
+                                else store16_s<SM, 3072>(base + (i >> 2) * 4096, lane * 16u, r[v][i]);
+                            }
+                    }
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     if (KP_ablate(a) & 2) break;

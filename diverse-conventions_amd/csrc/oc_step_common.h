@@ -257,6 +257,17 @@ __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
     else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(t));
     else *reinterpret_cast<u32x4_dword_aligned *>(dst) = t;
 }
+// The same store addressed as scalar base + 32-bit lane offset + immediate (IMM < 4096): no 64-bit vector address to form and
+// carry per store.  `sbase` must be wave-uniform.
+template <int SM, int IMM>
+__device__ __forceinline__ void store16_s(int8_t *sbase, uint32_t voff, uint4 v) {
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    if (SM == SM_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1 nt" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+}
 __device__ __forceinline__ void store4(int8_t *dst, uint32_t v) { *reinterpret_cast<uint32_t *>(dst) = v; }
 
 // Workgroup == one wavefront, and a wavefront's LDS operations execute in issue order, so lanes

@@ -12,7 +12,12 @@ cands = [tuple(int(v) for v in c.split(",")) for c in (sys.argv[3:] or ["32,4,8"
 params = get_base_layout_params(layout, 200)
 acts = torch.randint(0, 6, (64, 2, n), device="cuda", dtype=torch.int32)
 engines = []
-for kpw, gp, wpc in cands:
+for cand in cands:
+    kpw, gp, wpc = cand[:3]
+    if len(cand) > 3:                                     # 4th field: OC_FAST_FLUSH for this engine's specialised build
+        os.environ["OC_FAST_FLUSH"] = str(cand[3])
+    else:
+        os.environ.pop("OC_FAST_FLUSH", None)
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(kpw, gp, wpc)
     e.rollout(acts, 100)
@@ -22,4 +27,4 @@ for r in range(9):
     for i, e in enumerate(engines):
         res[i].append(e.rollout_timed(acts, 1000) * 1e3 / 1000)
 for c, r in zip(cands, res):
-    print(f"{layout} N={n} kpw,passes,wpc={c}: median {statistics.median(r):.3f} us  min {min(r):.3f}  max {max(r):.3f}")
+    print(f"{layout} N={n} kpw,passes,wpc[,fast flush]={c}: median {statistics.median(r):.3f} us  min {min(r):.3f}  max {max(r):.3f}")
