@@ -122,6 +122,16 @@ def test_abi_argument_checks_and_tile_plan():
     assert t.tolist() == [[0, 128, 2, 1], [128, 128, 2, 1], [256, 44, 2, 1], [300, 64, 5, 0]]
     with pytest.raises(native.OvercookedNativeError):
         plan_tiles([(0, 10, 0, 0)], 100)                     # not a multiple of 32
+    # the multi-grid entry refuses malformed calls before touching the GPU
+    M = native.OcPolicyMultiSlot
+    buf = (ctypes.c_int32 * 64)()
+    tiles = ctypes.cast((ctypes.addressof(buf) + 15) // 16 * 16, ctypes.c_void_p)
+    slots = (M * 2)()
+    assert L.oc_policy_forward_multi(None, 1, tiles, 4, 1, 4, 0, 0, None, None) == -1
+    assert L.oc_policy_forward_multi(slots, 0, tiles, 4, 1, 4, 0, 0, None, None) == -1 and b"slots" in L.oc_last_error()
+    assert L.oc_policy_forward_multi(slots, 9, tiles, 4, 1, 4, 0, 0, None, None) == -1
+    assert L.oc_policy_forward_multi(slots, 1, tiles, 4, 3, 4, 0, 0, None, None) == -1 and b"multiple" in L.oc_last_error()
+    assert L.oc_policy_forward_multi(slots, 1, tiles, 4, 1, 4, 0, 0, None, None) == -1          # slot 0 has no shape
 
 
 def _plan_multi(segs, costs, workgroups):
