@@ -136,7 +136,7 @@ __global__ void np_step_kernel(const NpArgs a) {
 // ref:165-259 lossless_state_encoding for every viewer, output order (W, H, C) (envs/overcooked2_env.py:324).
 // Block = one viewer x kTilesPerBlock consecutive flat tiles (kitchen-major, output order inside a kitchen): a contiguous
 // byte range of that viewer's plane, built in LDS one tile per thread and written out one byte per thread, lanes contiguous.
-constexpr int kTilesPerBlock = 128;
+constexpr int kTilesPerBlock = 256;          // one tile per thread
 constexpr int kNpThreads = 256;
 
 __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
     const int v = blockIdx.y, S = a.S, P = a.P, C = a.C, shift = 5 * P;
     const int64_t f0 = static_cast<int64_t>(blockIdx.x) * kTilesPerBlock, total = a.n * S;
     const int ntiles = static_cast<int>(min(static_cast<int64_t>(kTilesPerBlock), total - f0));
-    for (int i = threadIdx.x; i < kTilesPerBlock * 32 / 4; i += kNpThreads) reinterpret_cast<uint32_t *>(stage)[i] = 0u;
+    for (int i = threadIdx.x; i < kTilesPerBlock * 32 / 16; i += kNpThreads) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     if (threadIdx.x < ntiles) {
         // (flat tile indices fit 32 bits -- the host checks -- so this is one 32-bit division per thread; the (x, y) of an
