@@ -46,6 +46,8 @@ __device__ __forceinline__ int np_count(uint32_t o) { return static_cast<int>(((
 
 // ref:381-385 get_state_transition + the wrappers' done / reward / reset rule (envs/overcooked2_env.py:327-339,
 // pantheonrl_extension/vectorenv.py:369-370), one thread per kitchen.
+// (Staging the block's records through LDS for coalesced access was measured and is slower: 111 vs 109 us per step at 4 x 65 536
+// kitchens -- the index arithmetic of the copy loops and two barriers cost more than the scattered dword accesses, which L2 serves.)
 __global__ void np_step_kernel(const NpArgs a) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= a.n) return;
@@ -134,58 +136,100 @@ __global__ void np_step_kernel(const NpArgs a) {
 }
 
 // ref:165-259 lossless_state_encoding for every viewer, output order (W, H, C) (envs/overcooked2_env.py:324).
-// Block = one viewer x kTilesPerBlock consecutive flat tiles (kitchen-major, output order inside a kitchen): a contiguous
-// byte range of that viewer's plane, built in LDS one tile per thread and written out one byte per thread, lanes contiguous.
-constexpr int kTilesPerBlock = 256;          // one tile per thread
+// Block = `kpb` whole kitchens (as many as give at most kNpThreads tiles; an even number when S is odd, so that every block's
+// byte range in a viewer's plane starts on a dword).  The kitchens' records are copied into LDS first (consecutive dwords: coalesced),
+// every thread then encodes ONE tile for ALL viewers from there -- the terrain / object / held-object bytes are the same for every
+// viewer, only the player slots differ (ref:221-234) -- into one staging range per viewer, and the block writes the P contiguous
+// byte ranges out 16 bytes per lane.  (The first version ran one viewer per block straight from global memory: ~11 scattered
+// dword loads per thread and viewer, 168 us for 4 x 65 536 kitchens of multiplayer_schelling against 400 MB of planes.)
 constexpr int kNpThreads = 256;
+constexpr int kNpMaxC = 5 * kMaxP + 10;             // 30 bytes per tile with four players
+
+__host__ __device__ inline int np_kitchens_per_block(int S) {
+    int kpb = kNpThreads / S;
+    if (kpb < 1) kpb = 1;                            // (S <= 255 < kNpThreads, so this does not happen)
+    if ((S & 1) && kpb > 1) kpb &= ~1;               // kpb * S * C must be a multiple of 4 bytes: C is even, so kpb * S even
+    return kpb;
+}
+__host__ __device__ inline size_t np_encode_lds_bytes(int S, int P, int recd) {
+    const int kpb = np_kitchens_per_block(S), C = 5 * P + 10;
+    const size_t per_viewer = (static_cast<size_t>(kpb) * S * C + 15) / 16 * 16;
+    return static_cast<size_t>(kpb) * recd * 4 + 16 + per_viewer * P;
+}
 
 __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
-    __shared__ __attribute__((aligned(16))) int8_t stage[kTilesPerBlock * 32];
-    const int v = blockIdx.y, S = a.S, P = a.P, C = a.C, shift = 5 * P;
-    const int64_t f0 = static_cast<int64_t>(blockIdx.x) * kTilesPerBlock, total = a.n * S;
-    const int ntiles = static_cast<int>(min(static_cast<int64_t>(kTilesPerBlock), total - f0));
-    for (int i = threadIdx.x; i < kTilesPerBlock * 32 / 16; i += kNpThreads) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0u, 0u, 0u, 0u);
+    extern __shared__ __attribute__((aligned(16))) uint32_t np_lds[];
+    const int S = a.S, P = a.P, C = a.C, shift = 5 * P, recd = a.recd;
+    const int kpb = np_kitchens_per_block(S);
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x) * kpb;
+    const int nk = static_cast<int>(min(static_cast<int64_t>(kpb), a.n - k0));
+    const int ntiles = nk * S;
+    uint32_t *recs = np_lds;                                                   // [kpb][recd]
+    const int rec_dwords = (kpb * recd + 3) & ~3;
+    int8_t *stage = reinterpret_cast<int8_t *>(np_lds + rec_dwords);           // [P][per_viewer]
+    const int per_viewer = (kpb * S * C + 15) / 16 * 16;
+    // records -> LDS, staging ranges -> 0
+    for (int i = threadIdx.x; i < nk * recd; i += kNpThreads) recs[i] = a.state[k0 * recd + i];
+    for (int i = threadIdx.x; i < per_viewer * P / 16; i += kNpThreads) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     if (threadIdx.x < ntiles) {
-        // (flat tile indices fit 32 bits -- the host checks -- so this is one 32-bit division per thread; the (x, y) of an
-        // output tile comes from the table, not from two more)
-        const uint32_t f = static_cast<uint32_t>(f0) + threadIdx.x, k = f / static_cast<uint32_t>(S);
-        const int o = static_cast<int>(f - k * S), t = static_cast<int>(a.out_tab2[2 * o] & 0xff);
-        const uint32_t *rec = a.state + static_cast<int64_t>(k) * a.recd;
-        int8_t *b = stage + threadIdx.x * C;                                         // this tile's C bytes, already zero
+        const int k = threadIdx.x / S, o = threadIdx.x - k * S, t = static_cast<int>(a.out_tab2[2 * o] & 0xff);
+        const uint32_t *rec = recs + k * recd;
         const uint32_t terr = a.terrain[t], obj = rec[t];
-        if (terr > T_AIR) b[shift + terr - 1] = 1;                                   // ref:165-171
+        // viewer-independent bytes of this tile: (channel, value) pairs, at most four
+        int ch[4], val[4], nb = 0;
+        if (terr > T_AIR) { ch[nb] = shift + static_cast<int>(terr) - 1; val[nb++] = 1; }           // ref:165-171
         const uint32_t name = obj & 0xff;
-        if (name == O_SOUP) {                                                        // ref:182-203
-            if (terr == T_POT) { b[shift + 5] = static_cast<int8_t>((obj >> 8) & 0xff); b[shift + 6] = static_cast<int8_t>(max(np_tick(obj), 0)); }
-            else b[shift + 7] = 1;
-        } else if (name == O_DISH) b[shift + 8] = 1;                                 // ref:205-207
-        else if (name == O_ONION) b[shift + 9] = 1;                                  // ref:209-211
-        int other = 1;
-        for (int i = 0; i < P; ++i) {                                                // ref:220-257
+        bool soup = false, dish = false, onion = false;
+        if (name == O_SOUP) {                                                                      // ref:182-203
+            if (terr == T_POT) {
+                ch[nb] = shift + 5; val[nb++] = static_cast<int>((obj >> 8) & 0xff);
+                ch[nb] = shift + 6; val[nb++] = max(np_tick(obj), 0);
+            } else soup = true;
+        } else if (name == O_DISH) dish = true;                                                    // ref:205-207
+        else if (name == O_ONION) onion = true;                                                    // ref:209-211
+        // players standing here (ref:220-257): their held objects are viewer-independent too
+        uint32_t here = 0;                                                                         // bit i: player i on this tile
+        uint32_t oris = 0;                                                                         // 2 bits per player
+        for (int i = 0; i < P; ++i) {
             const uint32_t pp = rec[S + i];
-            const int slot = i == v ? 0 : other++;
             if (static_cast<int>(pp & 0xff) != t) continue;
-            b[slot] = 1;
-            b[P + 4 * slot + ((pp >> 8) & 3)] = 1;
+            here |= 1u << i;
+            oris |= ((pp >> 8) & 3u) << (2 * i);
             const uint32_t h = rec[S + P + i] & 0xff;
-            if (h == O_SOUP) b[shift + 7] = 1;
-            else if (h == O_DISH) b[shift + 8] = 1;
-            else if (h == O_ONION) b[shift + 9] = 1;
+            soup |= h == O_SOUP; dish |= h == O_DISH; onion |= h == O_ONION;
+        }
+        for (int v = 0; v < P; ++v) {
+            int8_t *b = stage + v * per_viewer + threadIdx.x * C;                                  // this tile's C bytes, already zero
+            for (int j = 0; j < nb; ++j) b[ch[j]] = static_cast<int8_t>(val[j]);
+            if (soup) b[shift + 7] = 1;
+            if (dish) b[shift + 8] = 1;
+            if (onion) b[shift + 9] = 1;
+            if (here) {
+                int other = 1;
+                for (int i = 0; i < P; ++i) {
+                    const int slot = i == v ? 0 : other++;
+                    if (!(here & (1u << i))) continue;
+                    b[slot] = 1;
+                    b[P + 4 * slot + ((oris >> (2 * i)) & 3)] = 1;
+                }
+            }
         }
     }
     __syncthreads();
-    // the block's bytes are one contiguous range of the viewer's plane: 16 bytes per lane where the plane is dword aligned (a
-    // 16-byte store needs no more on gfx950, see store16), single bytes otherwise and for the last few
-    int8_t *dst = a.obs + v * a.obs_player_stride + f0 * C;
+    // every viewer's range is contiguous in its plane and starts on a dword (16-byte stores need no more on gfx950, see store16)
     const int nbytes = ntiles * C;
-    int done_bytes = 0;
-    if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
-        const int n16 = nbytes >> 4;
-        for (int i = threadIdx.x; i < n16; i += kNpThreads) store16<SM_PLAIN>(dst + 16 * i, reinterpret_cast<const uint4 *>(stage)[i]);
-        done_bytes = n16 << 4;
+    for (int v = 0; v < P; ++v) {
+        int8_t *dst = a.obs + v * a.obs_player_stride + k0 * S * C;
+        const int8_t *src = stage + v * per_viewer;
+        int done_bytes = 0;
+        if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+            const int n16 = nbytes >> 4;
+            for (int i = threadIdx.x; i < n16; i += kNpThreads) store16<SM_PLAIN>(dst + 16 * i, reinterpret_cast<const uint4 *>(src)[i]);
+            done_bytes = n16 << 4;
+        }
+        for (int i = done_bytes + threadIdx.x; i < nbytes; i += kNpThreads) dst[i] = src[i];
     }
-    for (int i = done_bytes + threadIdx.x; i < nbytes; i += kNpThreads) dst[i] = stage[i];
 }
 
 // every kitchen to the standard start state (ref:387-391)
