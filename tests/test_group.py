@@ -25,7 +25,10 @@ def test_group_module_compiles_and_plan_gives_one_group_per_wavefront(layout_par
         S = p["width"] * p["height"]
         assert kpw % 4 == 0 and 4 <= kpw <= 64 and (kpw * S * 5) % 4 == 0
         assert blocks == -(-8192 // kpw), "config 3 fits one group per wavefront: nobody gets two"
-        tiles.append(kpw * S)
+        if S <= 32:
+            assert kpw in (16, 32), "small grids take 16 or 32 kitchens per group (batched flush), whatever the tile balance says"
+        else:
+            tiles.append(kpw * S)
     assert sum(b for _, b in plan) <= 12 * 256
     even = sum(8192 * p["width"] * p["height"] for p in ps) / (12 * 256)         # tiles per wavefront of a perfect split
     # groups come in steps of 4 kitchens, so the best reachable budget sits within one step (4 x the largest grid) of an even split
