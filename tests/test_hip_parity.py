@@ -255,6 +255,38 @@ def test_reset_all_and_rollout_time_major(layout_params):
     eng.close()
 
 
+def test_time_major_steps_of_a_large_small_grid_batch_use_their_own_geometry(layout_params):
+    """32 768 cramped_room kitchens take 32 kitchens per group in place and keep 16 for fresh destinations (a module of its own,
+    built on the first such step): in-place steps, time-major steps and in-place steps again against the oracle on a sample of
+    kitchens from every part of the batch (kitchens are independent, so the oracle steps just those)."""
+    params = layout_params["simple"]
+    n, T = 32768, 9
+    rng = np.random.default_rng(12)
+    pick = np.unique(np.concatenate([np.arange(70), rng.integers(0, n, 300), np.arange(n - 70, n), np.arange(16352, 16416)]))
+    acts = rng.integers(0, 6, size=(3 * T, 2, n)).astype(np.int32)
+    dacts = torch.from_numpy(acts).cuda()
+    eng = _engine(params, n)
+    assert "kpw 32" in eng.kernel_build_info
+    ora = oracle.OracleVecEnv(params, len(pick))
+    slots = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    t = 0
+    for phase in ("in place", "time major", "in place"):
+        if phase == "time major":
+            eng.rollout(dacts[t:t + T], T, obs=slots, reward=rew, done=done)
+        for i in range(T):
+            oobs, orew, odone = ora.step(acts[t + i][:, pick])
+            if phase == "time major":
+                got, grew, gdone = slots[i], rew[i], done[i]
+            else:
+                got, grew, gdone = eng.step(dacts[t + i])
+            assert np.array_equal(got[:, pick].cpu().numpy(), oobs), (phase, i)
+            assert np.array_equal(grew[:, pick].cpu().numpy(), orew) and np.array_equal(gdone[pick].cpu().numpy(), odone)
+        t += T
+    eng.close()
+
+
 def test_full_size_properties(layout_params):
     """65 536 kitchens (BASELINE.json's size): size-independent checks.
     (1) replication: kitchens fed identical action streams stay identical to kitchen 0;
