@@ -691,32 +691,38 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         }
         // actor: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80), then argmax (mode) or
         // a Gumbel-max draw
-        float mx = -INFINITY;
+        // (branch-free over the lane's four outputs: the ones past n_out count as -inf -- exp gives 0, the key never wins -- so
+        // the lane halves, which own different numbers of valid outputs, run one straight instruction stream)
+        float x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) mx = fmaxf(mx, out[r]);
+        for (int r = 0; r < 4; ++r) x[r] = 4 * h + r < n_out ? out[r] : -INFINITY;
+        float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * h + r < n_out) sum += __expf(out[r] - mx);      // v_exp_f32: relative error ~1e-7 on arguments <= 0
+        for (int r = 0; r < 4; ++r) sum += __expf(x[r] - mx);          // v_exp_f32: relative error ~1e-7 on arguments <= 0
         sum += __shfl_xor(sum, 32);
         const float lse = mx + __logf(sum);                          // sum in [1, n_out]: absolute error ~2e-7
         int best = 0;
         float best_key = -INFINITY, best_lp = 0.f;
+        float lps[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * h + r;
-            if (i < n_out) {
-                const float lp = out[r] - lse;
-                float key = lp;
-                if (a.sample) {                                       // the noise needs no more than the fast logarithm
-                    const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), i));
-                    key = lp - __logf(-__logf(u));
-                }
-                if (key > best_key) { best_key = key; best = i; best_lp = lp; }
-                if (valid && S.logp) S.logp[row * n_out + i] = lp;
+            const float lp = x[r] - lse;
+            float key = lp;
+            if (a.sample) {                                           // the noise needs no more than the fast logarithm
+                const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), i));
+                key = lp - __logf(-__logf(u));
             }
+            const bool wins = key > best_key;
+            best_key = wins ? key : best_key; best = wins ? i : best; best_lp = wins ? lp : best_lp;
+            lps[r] = lp;
+        }
+        if (valid && S.logp) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * h + r < n_out) S.logp[row * n_out + 4 * h + r] = lps[r];
         }
         {
             const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
