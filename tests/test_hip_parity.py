@@ -256,13 +256,14 @@ def test_reset_all_and_rollout_time_major(layout_params):
 
 
 def test_time_major_steps_of_a_large_small_grid_batch_use_their_own_geometry(layout_params):
-    """32 768 cramped_room kitchens take 32 kitchens per group in place and keep 16 for fresh destinations (a module of its own,
-    built on the first such step): in-place steps, time-major steps and in-place steps again against the oracle on a sample of
-    kitchens from every part of the batch (kitchens are independent, so the oracle steps just those)."""
+    """49 152 cramped_room kitchens take 32 kitchens per group in place; steps into fresh destinations run with 16 per group on
+    eight wavefronts per CU from a module of their own, built on the first such step: in-place steps, time-major steps and in-place
+    steps again against the oracle on a sample of kitchens from every part of the batch (kitchens are independent, so the oracle
+    steps just those)."""
     params = layout_params["simple"]
-    n, T = 32768, 9
+    n, T = 49152, 9
     rng = np.random.default_rng(12)
-    pick = np.unique(np.concatenate([np.arange(70), rng.integers(0, n, 300), np.arange(n - 70, n), np.arange(16352, 16416)]))
+    pick = np.unique(np.concatenate([np.arange(70), rng.integers(0, n, 300), np.arange(n - 70, n), np.arange(24544, 24608)]))
     acts = rng.integers(0, 6, size=(3 * T, 2, n)).astype(np.int32)
     dacts = torch.from_numpy(acts).cuda()
     eng = _engine(params, n)
