@@ -8,6 +8,11 @@
 One rank per GPU, each owning `--kitchens` kitchens (weak scaling: kitchens are independent, the
 rollout has no data-path collective).  A step = one launch of the fused kernel over every kitchen of
 the rank with synthetic uniform-random joint actions already resident in HBM.  Prints ONE JSON line.
+
+Secondary figures (never `value`) run with their OWN fixed step counts and warm-ups, whatever --steps says, so that a
+short driver run and a long profiling run report the same things.  With more than one rank (or OC_BENCH_FORCE_DIST=1) the
+`exchange` secondary times the one real collective of a sharded run: BASELINE config 4's per-GPU compact trajectory through
+`TrajectoryExchange.gather_trajectory` (ONE all_gather_into_tensor: RCCL over xGMI) and `featurize_all`.
 """
 import argparse
 import json
@@ -20,6 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (same guide); a GPU has 7, one per peer
+SEC_STEPS, SEC_WARMUP = 1000, 100   # every secondary figure: its own fixed counts, independent of --steps / --warmup
 
 
 def algorithmic_bytes(S, P=2):
@@ -98,6 +105,177 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
                                                   "note": "reference SimplifiedOvercooked.n_step, BASELINE.md section 2 (other host)"}}
 
 
+def _checksum(t):
+    """Position-sensitive checksum of an int8 tensor (numel a multiple of 4): (sum of words, sum of words x (1 + index mod 8191))
+    as Python ints; temporaries are 2x the tensor."""
+    import torch
+    w = t.contiguous().view(-1).view(torch.int32).to(torch.int64)
+    k = torch.arange(w.numel(), device=w.device, dtype=torch.int64).remainder_(8191).add_(1)
+    return int(w.sum()), int((w * k).sum())
+
+
+def check_distinct_devices(idents, allow_shared=False):
+    """One rank per GPU is the contract of a multi-GPU run: two ranks that report the same device (uuid where the runtime gives
+    one, else the device index) end the run loudly -- unless the OC_BENCH_DEVICE test hook pinned them there on purpose."""
+    keys = [(d.get("uuid") or d["device_index"]) for d in idents]
+    if len(set(keys)) != len(idents) and not allow_shared:
+        raise SystemExit(f"exchange: {len(idents)} ranks but only {len(set(keys))} distinct devices ({idents}); one rank per GPU is the contract")
+    return len(set(keys))
+
+
+def exchange_leg(world, rank, local, backend, gen, c4_step_s):
+    """The one real collective of a sharded run (consumer: the reference's XP / MP losses read whole buffers,
+    train/XD/xd.py:311-397): every rank's compact trajectory of BASELINE config 4 -- asymmetric_advantages, 65 536 / world
+    kitchens, T = 200 steps of [state records | actions | reward | done] -- through TrajectoryExchange.gather_trajectory (ONE
+    all_gather_into_tensor) and the receive side, featurize_all (one oc_encode_trajectory launch per peer).  Timed with events on
+    the current stream after a full warm-up exchange; checked: every peer's re-featurised block against checksums its owner took
+    of the observations its own engine wrote during the rollout.  Returns the dict for the JSON line (same on every rank)."""
+    import torch
+    import torch.distributed as dist
+    from diverse_conventions_amd import OvercookedEngine, TrajectoryExchange, get_base_layout_params
+    total = 65536
+    T = int(os.environ.get("OC_BENCH_EXCHANGE_T", "200"))            # test hook: a shorter trajectory
+    n = total // world
+    params = get_base_layout_params("asymmetric_advantages", 200)
+    eng = OvercookedEngine(params, n, local)
+    dev = eng.device
+    r4 = eng.record_bytes // 4
+    rec = torch.empty((T, n, r4), dtype=torch.int32, device=dev)
+    rew = torch.empty((T, 2, n), dtype=torch.int32, device=dev)
+    done = torch.empty((T, n), dtype=torch.int32, device=dev)
+    acts = torch.randint(0, 6, (T, 2, n), generator=gen, device=dev, dtype=torch.int32)
+    eng.stagger()                                                    # episode phases spread out: resets all along the trajectory
+    probe_t = sorted({0, T // 2, T - 1})
+    own_sums = {}
+    for t in range(T):                                               # the rollout that fills the shard (not timed here)
+        eng.export_states(out=rec[t])
+        if t in probe_t:
+            own_sums[t] = _checksum(eng.observe())                   # what this rank's engine says slot t looks like
+        eng.step(acts[t], reward=rew[t], done=done[t])
+    torch.cuda.synchronize()
+    # control plane: who is where (fails loudly when two ranks share a device and that was not asked for)
+    ident = {"rank": rank, "device_index": local, "name": torch.cuda.get_device_name(local)}
+    try:
+        ident["uuid"] = str(torch.cuda.get_device_properties(local).uuid)
+    except Exception:                                                 # noqa: BLE001
+        ident["uuid"] = None
+    try:
+        free, tot = torch.cuda.mem_get_info(local)
+        ident["hbm_GB"] = round(tot / 1e9, 1)
+    except Exception:                                                 # noqa: BLE001
+        pass
+    idents, sums_all = [None] * world, [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(idents, ident)
+        dist.all_gather_object(sums_all, own_sums)
+    else:
+        idents, sums_all = [ident], [own_sums]
+    check_distinct_devices(idents, allow_shared="OC_BENCH_DEVICE" in os.environ)
+    # gloo (test hook OC_BENCH_BACKEND) moves host buffers; RCCL moves the device buffers as they are
+    on_host = backend != "nccl"
+    ex = TrajectoryExchange(always_collective=True)
+    fields = (rec, acts, rew[:, 0].contiguous(), done)
+    if on_host:
+        fields = tuple(f.cpu() for f in fields)
+    words = sum(f.numel() for f in fields)
+    sent_bytes = 4 * (words + (-words) % 4)
+    out = torch.empty((T, 2, world * n, eng.width, eng.height, 20), dtype=torch.int8, device=dev)
+
+    def once():
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        got = ex.gather_trajectory(*fields)
+        e1.record()
+        if on_host:                                                   # events see nothing of a gloo transfer of host buffers
+            wall = time.perf_counter() - t0
+            records_all = got["records"].to(dev)
+        else:
+            records_all = got["records"]
+        e2.record()
+        ex.featurize_all(eng, records_all, out=out)
+        e3.record()
+        torch.cuda.synchronize()
+        return got, (wall * 1e3 if on_host else e0.elapsed_time(e1)), e2.elapsed_time(e3)
+
+    once()                                                            # warm-up: communicator set-up, allocations, code objects
+    reps = 3
+    runs = [once() for _ in range(reps)]
+    got = runs[-1][0]
+    gather_ms = sum(r[1] for r in runs) / reps
+    feat_ms = sum(r[2] for r in runs) / reps
+    # check: own fields come back at index `rank`, and every peer's block of the re-featurised tensor has the checksum its owner
+    # computed from its own engine's observation of that slot
+    ok = all(torch.equal(got[k][rank], f) for k, f in zip(("records", "actions", "reward", "done"), fields))
+    for r in range(world):
+        for t in probe_t:
+            ok = ok and _checksum(out[t, :, r * n:(r + 1) * n]) == tuple(sums_all[r][t])
+    stats = torch.tensor([gather_ms, feat_ms, 0.0 if ok else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if dist.is_initialized():
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    gather_ms, feat_ms, bad = (float(x) for x in stats)
+    eng.close()
+    del out
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                                 # noqa: BLE001
+        rccl_version = None
+    update_s = T * c4_step_s + gather_ms / 1e3 + feat_ms / 1e3
+    return {
+        "what": f"BASELINE config 4's per-update exchange: asymmetric_advantages, {total} kitchens in total = {n} per GPU, T = {T} compact "
+                "steps (state records + actions + reward + done, 4S+16+16 B per kitchen-step) through ONE all_gather_into_tensor, then "
+                "every peer's shard re-featurised on the receiver (oc_encode_trajectory, one launch per peer)",
+        "steps": T, "kitchens_per_gpu": n, "collectives_per_update": 1, "reps": reps,
+        "MB_sent_per_gpu": sent_bytes / 1e6, "MB_received_per_gpu": sent_bytes * (world - 1) / 1e6,
+        "exchange_ms": gather_ms, "GBps_per_gpu_sent": sent_bytes * max(world - 1, 1) / gather_ms / 1e6,
+        "model_ms_direct_all_gather": sent_bytes / XGMI_LINK_GBS / 1e6,
+        "model_note": f"direct all-gather: a GPU pushes its shard to each peer over that peer's own xGMI link ({XGMI_LINK_GBS:.0f} GB/s each, "
+                      "all links at once), so the model time is shard bytes / one link whatever the world size; a single ring would take (world-1) x that",
+        "refeaturize_ms": feat_ms, "refeaturize_GB_written": T * 2 * world * n * eng.size * 20 / 1e9,
+        "refeaturize_GBps": T * 2 * world * n * eng.size * 20 / feat_ms / 1e6,
+        "checked": bad == 0.0,
+        "rccl": {"backend": backend if dist.is_initialized() else None, "world": world, "version": rccl_version,
+                 "transport": "device buffers" if not on_host else "host buffers (gloo test hook)", "devices": idents},
+        "update_amortised_value": 2 * total * T / update_s, "update_amortised_unit": "agent-env steps/s",
+        "update_amortised_note": f"config 4 over one PPO update: {T} env steps at the config4_split step time + one exchange + the "
+                                 "re-featurisation, whole job",
+    }
+
+
+def check_policy_in_loop(ro, eng, params, T=24, blocks=4, per_block=64):
+    """Outside every timed region: T more steps of the policies-in-the-loop rollout recorded into a trajectory, then `blocks` x
+    `per_block` kitchens (spread over the pairing segments) replayed through the CPU oracle from their exported start states
+    with the recorded actions -- observations, rewards and dones must be bit-identical."""
+    import numpy as np
+    import torch
+    from diverse_conventions_amd import TrajectoryBuffer
+    from oracle import oracle
+    n = eng.num_kitchens
+    firsts = [int(i * (n - per_block) / max(blocks - 1, 1)) for i in range(blocks)]
+    starts = [eng.get_state(f, per_block) for f in firsts]
+    traj = TrajectoryBuffer(eng, T)
+    ro.collect(traj)
+    torch.cuda.synchronize()
+    for f, (tiles, players, ts) in zip(firsts, starts):
+        ora = oracle.OracleVecEnv(params, per_block)
+        ora.set_state(tiles, players, ts)
+        sl = slice(f, f + per_block)
+        if not np.array_equal(traj.obs[0][:, sl].cpu().numpy(), ora.encode()):
+            return False
+        for t in range(T):
+            a = traj.actions[t][:, sl].cpu().numpy()
+            if a.min() < 0 or a.max() > 5:
+                return False
+            oobs, orew, odone = ora.step(np.ascontiguousarray(a))
+            if not (np.array_equal(traj.obs[t + 1][:, sl].cpu().numpy(), oobs) and np.array_equal(traj.reward[t][:, sl].cpu().numpy(), orew)
+                    and np.array_equal(traj.done[t][sl].cpu().numpy(), odone)):
+                return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,21 +338,21 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     fused_ms = tm_us = c4_wall = c4_kernel_ms = float("nan")
-    slots, c4_total, c4_n, c4_S, c4_steps, c3 = 64, 65536, 65536 // world, 45, 1, None
+    slots, c4_total, c4_n, c4_S, c4_steps, c3 = 64, 65536, 65536 // world, 45, SEC_STEPS, None
     if not args.no_secondary:
-        # Secondary figure, never `value`: the same K steps as ONE launch (oc_rollout_fused: per-kitchen state stays in
+        # Secondary figure, never `value`: SEC_STEPS steps as ONE launch (oc_rollout_fused: per-kitchen state stays in
         # LDS between steps, same action tape read from HBM every step, every step's obs/reward/done written).
         # Only usable when actions are known ahead, which is exactly this synthetic rollout; a policy in the loop
         # needs the one-launch-per-step path that `value` measures.
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        eng.rollout_fused(min(args.steps, 200), actions=actions)
+        eng.rollout_fused(SEC_WARMUP, actions=actions)
         ev0.record()
-        eng.rollout_fused(args.steps, actions=actions)
+        eng.rollout_fused(SEC_STEPS, actions=actions)
         ev1.record()
         torch.cuda.synchronize()
         fused_ms = ev0.elapsed_time(ev1)
-        # Secondary figure, never `value`: HBM proper.  The same K launches with every step's observations / rewards / dones
+        # Secondary figure, never `value`: HBM proper.  The same launches with every step's observations / rewards / dones
         # written to their own time-major trajectory slot (what a rollout buffer wants): 64 slots x 52 MB are
         # far beyond the 256 MB Infinity Cache, so no byte is absorbed on-die (the in-place buffer of `value` is the
         # reference's data-plane contract -- the simulator's persistent output tensors, overwritten every step -- and fits it).
@@ -183,8 +361,9 @@ def main():
         tm_obs = torch.empty((slots,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
         tm_rew = torch.empty((slots, 2, n), dtype=torch.int32, device="cuda")
         tm_done = torch.empty((slots, n), dtype=torch.int32, device="cuda")
-        eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
-        tm_rounds = max(1, min(args.steps, 640) // slots)
+        for _ in range(2):
+            eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
+        tm_rounds = max(1, SEC_STEPS // slots)
         ev0.record()
         for _ in range(tm_rounds):
             eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
@@ -202,8 +381,8 @@ def main():
         c4_S = c4_params["width"] * c4_params["height"]
         eng4 = OvercookedEngine(c4_params, c4_n, local)
         act4 = torch.randint(0, 6, (t_act, 2, c4_n), generator=gen, device="cuda", dtype=torch.int32)
-        c4_steps = min(args.steps, 1000)
-        eng4.rollout(act4, min(args.warmup, 100))
+        c4_steps = SEC_STEPS
+        eng4.rollout(act4, SEC_WARMUP)
         barrier()
         t4 = time.perf_counter()
         c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
@@ -218,12 +397,12 @@ def main():
             from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup
             grp = EngineGroup.from_layouts(CLASSIC_LAYOUTS, 8192, local)
             act3 = [torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32) for _ in grp.engines]
-            grp.rollout_timed(act3, 50)
-            c3_steps = min(args.steps, 1000)
+            grp.rollout_timed(act3, SEC_WARMUP)
+            c3_steps = SEC_STEPS
             c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
             c3_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
             c3 = {"what": "BASELINE config 3 env step: 5 classic layouts x 8192 kitchens, ONE launch per joint step (oc_group_step)",
-                  "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
+                  "steps": c3_steps, "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
                   "bytes_per_launch": c3_bytes, "achieved_GBps": c3_bytes / c3_us / 1e3, "frac_of_8TBps": c3_bytes / c3_us / 1e3 / HBM_PEAK_GBS,
                   "build": grp.build_info}
             grp.close(close_engines=True)
@@ -236,21 +415,27 @@ def main():
     wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms = (float(x) for x in stats)
     fused_bytes = n * (2 * S * 20 + 8 + 8 + 4)            # obs + i32 actions + reward + done; no state round trip
     fused = {"what": "same steps as one launch (state resident in LDS), action tape in HBM, outputs in place",
-             "us_per_step": fused_ms * 1e3 / args.steps, "value": 2 * n * world * args.steps / (fused_ms / 1e3),
+             "steps": SEC_STEPS, "us_per_step": fused_ms * 1e3 / SEC_STEPS, "value": 2 * n * world * SEC_STEPS / (fused_ms / 1e3),
              "unit": "agent-env steps/s", "bytes_per_step": fused_bytes,
-             "achieved_GBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9,
-             "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+             "achieved_GBps": fused_bytes / (fused_ms / 1e3 / SEC_STEPS) / 1e9,
+             "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / SEC_STEPS) / 1e9 / HBM_PEAK_GBS}
     hbm_proper = {"what": f"the headline workload with every step's outputs written to their own time-major slot ({slots} slots, "
                           f"{slots * 2 * n * S * 20 / 1e9:.1f} GB: beyond the 256 MB Infinity Cache), one launch per step, non-temporal plane stores",
-                  "us_per_launch": tm_us, "value": 2 * n * world / tm_us * 1e6, "unit": "agent-env steps/s",
+                  "steps": max(1, SEC_STEPS // slots) * slots, "us_per_launch": tm_us, "value": 2 * n * world / tm_us * 1e6, "unit": "agent-env steps/s",
                   "achieved_GBps": algorithmic_bytes(S) * n / tm_us / 1e3, "frac_of_8TBps": algorithmic_bytes(S) * n / tm_us / 1e3 / HBM_PEAK_GBS}
     c4_us = c4_kernel_ms * 1e3 / c4_steps
     config4_split = {"what": f"BASELINE config 4's split (strong scaling): asymmetric_advantages, {c4_total} kitchens in total = {c4_n} per GPU "
                              f"on {world} GPU(s), one launch per step, outputs in place",
-                     "kitchens_per_gpu": c4_n, "us_per_launch": c4_us, "value": 2 * c4_n * world * c4_steps / c4_wall,
+                     "steps": c4_steps, "kitchens_per_gpu": c4_n, "us_per_launch": c4_us, "value": 2 * c4_n * world * c4_steps / c4_wall,
                      "unit": "agent-env steps/s", "scaling": "strong",
                      "achieved_GBps_per_gpu": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3,
                      "frac_of_8TBps": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3 / HBM_PEAK_GBS}
+
+    # Secondary figure, never `value`: the per-update trajectory exchange -- the one place the north star's collective meets a
+    # clock.  Runs whenever a process group exists (world > 1, or OC_BENCH_FORCE_DIST=1 with one rank).
+    exchange = None
+    if use_dist and not args.no_secondary:
+        exchange = exchange_leg(world, rank, local, backend, gen, c4_wall / c4_steps)
 
     # Secondary figure, never `value`: policies in the loop.  8 conventions in the reference's 15 pairing
     # segments, every actor on both sides evaluated by ONE fused MFMA launch (oc_policy_forward) per step + the env launch;
@@ -271,9 +456,9 @@ def main():
           nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=sds)
           eng2 = OvercookedEngine(params, threads * (2 * k + 1), local)
           ro = FusedPairedRollout(eng2, nets, threads, k)
-          ro.step(20)
+          ro.step(SEC_WARMUP)
           torch.cuda.synchronize()
-          psteps = min(args.steps, 300)
+          psteps = SEC_STEPS
           pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
           pe0.record()
           for _ in range(psteps):
@@ -291,8 +476,11 @@ def main():
           bound_us = cycles / (4 * cus) / 2400.0
           policy = {"what": f"{k + 1} conventions in {2 * k + 1} pairing segments of {threads} kitchens: every actor, both sides, in one "
                             "fused MFMA launch per step + the env launch (FusedPairedRollout); random-weight reference-shape networks",
-                    "kitchens": eng2.num_kitchens, "us_per_step": step_us, "value": 2 * eng2.num_kitchens / step_us * 1e6,
+                    "steps": psteps, "kitchens": eng2.num_kitchens, "us_per_step": step_us, "value": 2 * eng2.num_kitchens / step_us * 1e6,
                     "unit": "agent-env steps/s",
+                    "checked": check_policy_in_loop(ro, eng2, params),
+                    "checked_note": "after the timed steps: 24 more steps recorded into a trajectory, 4 x 64 kitchens spread over the pairing "
+                                    "segments replayed through the CPU oracle with the recorded actions (obs, reward, done bit-identical)",
                     "policy_kernel": {"kernel": "oc_policy_kernel<4 digits>", "us_per_launch": pol_us, "network_evaluations": rows,
                                       "useful_TFLOPs": rows * 2 * (P * 180 * 32 + P * 32 * 64 + 64 * 64 + 64 * 6) / pol_us * 1e-6,
                                       "bound": "mfma", "issue_bound_us_at_2.4GHz": bound_us, "frac": bound_us / pol_us,
@@ -319,6 +507,14 @@ def main():
             traffic = entry.get("bytes_per_launch")
             if traffic is not None:
                 traffic_source = f"profiles/hbm_traffic.json ({entry.get('measured', 'round unknown')}): {entry.get('source', '')}"
+        # the rocprofv3 --kernel-trace --stats average of the headline kernel on this very workload (committed summary of a
+        # 2000-step run, profiles/kernel_us.json names the csv): the short driver run and the long profile in one record
+        kernel_us_profile, kernel_us_profile_source = None, None
+        kpath = os.path.join(ROOT, "profiles", "kernel_us.json")
+        if os.path.exists(kpath):
+            with open(kpath) as f:
+                kj = json.load(f).get(f"{args.layout}:{n}", {})
+            kernel_us_profile, kernel_us_profile_source = kj.get("avg_us"), kj.get("source")
         out = {
             "metric": "agent-env steps/sec at 64k parallel kitchens, 1/2/4/8 MI355X",
             "value": 2 * n * world * args.steps / wall,
@@ -335,11 +531,18 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "oc_jit_step_i32_v16" if "specialised" in build_info else "oc_step_kernel<STEP,i32,vec16>",
                          "kernel_build": build_info, "bytes_per_launch": bytes_per_launch,
-                         "us_per_launch": per_launch_s * 1e6},
+                         "us_per_launch": per_launch_s * 1e6, "kernel_us_profile": kernel_us_profile,
+                         "kernel_us_profile_source": kernel_us_profile_source},
         }
         if not args.no_secondary:
+            # the same roofline object for the HBM-proper leg: nothing of its 3.4 GB of destinations fits the 256 MB Infinity Cache
+            out["roofline_hbm_proper"] = {"bound": "hbm", "achieved": hbm_proper["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": hbm_proper["frac_of_8TBps"], "us_per_launch": tm_us, "bytes_per_launch": bytes_per_launch,
+                                          "kernel": "oc_jit_step_i32_v16_nt (time-major slots, non-temporal plane stores)", "traffic": None}
             out["hbm_proper"] = hbm_proper
             out["config4_split"] = config4_split
+            if exchange is not None:
+                out["exchange"] = exchange
             if c3 is not None:
                 out["config3_one_launch"] = c3
             out["fused_rollout"] = fused

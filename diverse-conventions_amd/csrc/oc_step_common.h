@@ -241,7 +241,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     otherwise a serial tail of bytes / 6 TB/s behind the last wavefront (MI355X_MICROARCH.md, "boundary" row).
 // The write-through forms have no builtin for 16-byte stores, hence the inline asm; nothing in the kernel reads what
 // these stores write, so the asm needs no memory clobber, and stores the compiler does not count only make its own
-// vmcnt waits more conservative (vmcnt retires in order).
+// vmcnt waits more conservative (vmcnt retires in order).  Every asm store is followed by `s_nop 0`: the hazard
+// recogniser does not look inside asm, and gfx9-family parts need one wait state between a store of more than 64 bits
+// and a VALU write of its data registers (the 12-dword-store hazard) -- the step body is compiled anew per layout and
+// tuning, so the register allocation around the flush is not the same in every build.
 enum : int { SM_PLAIN = 0, SM_NT = 1, SM_SC1 = 2, SM_SC0SC1 = 3, SM_SC1_NT = 4 };
 // The destination is 16-byte aligned relative to its viewer plane, and a plane is only guaranteed 4-byte alignment (the
 // second viewer's plane of 8190 kitchens of a 5x5 grid starts 8 bytes off): gfx950 under ROCm runs compute queues in
@@ -252,9 +255,9 @@ template <int SM>
 __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
     const u32x4 t = {v.x, v.y, v.z, v.w};
     if (SM == SM_NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4_dword_aligned *>(dst));
-    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(t));
-    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(t));
-    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(t));
+    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(dst), "v"(t));
+    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" : : "v"(dst), "v"(t));
+    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" : : "v"(dst), "v"(t));
     else *reinterpret_cast<u32x4_dword_aligned *>(dst) = t;
 }
 // The same store addressed as scalar base + 32-bit lane offset + immediate (IMM < 4096): no 64-bit vector address to form and
@@ -262,11 +265,11 @@ __device__ __forceinline__ void store16(int8_t *dst, uint4 v) {
 template <int SM, int IMM>
 __device__ __forceinline__ void store16_s(int8_t *sbase, uint32_t voff, uint4 v) {
     const u32x4 t = {v.x, v.y, v.z, v.w};
-    if (SM == SM_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
-    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
-    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
-    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1 nt" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    if (SM == SM_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 0" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 0" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC0SC1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1\n\ts_nop 0" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else if (SM == SM_SC1_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1 nt\n\ts_nop 0" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 0" : : "v"(voff), "v"(t), "s"(sbase), "n"(IMM) : "memory");
 }
 __device__ __forceinline__ void store4(int8_t *dst, uint32_t v) { *reinterpret_cast<uint32_t *>(dst) = v; }
 

@@ -308,13 +308,23 @@ class OvercookedEngine:
             raise ValueError("checkpoint was taken from an engine of another size")
         if any(sd["layout"][k] != (list(v) if isinstance(v, (list, tuple)) else v) for k, v in self.params.items()):
             raise ValueError("checkpoint was taken from another layout")
-        # device path: one upload, one checking kernel (oc_import_states_checked), one scalar read-back
+        # device path, all or nothing: one upload, one validating kernel that writes nothing (oc_validate_states), one scalar
+        # read-back, and the copy only when every record passed -- a bad checkpoint leaves the engine exactly as it was
         rec = sd["records"].contiguous().to(self.device, dtype=torch.int32)
-        rejected = self.import_states_checked(rec)
+        rejected = self.validate_states(rec)
         if rejected:
             raise native.OvercookedNativeError(-1, f"{rejected} checkpoint record(s) have a player off the interior grid, a bad "
-                                                   "orientation or an unknown object code; nothing of them was loaded")
+                                                   "orientation or an unknown object code; the engine's state is unchanged")
+        self.import_states(rec)
         self.observe()
+
+    def validate_states(self, records) -> int:
+        """Number of `records` (device tensor in the engine's record format, any player count) the checked import would refuse;
+        touches nothing."""
+        count = records.numel() * records.element_size() // self.record_bytes
+        rejected = torch.zeros(1, dtype=torch.int32, device=self.device)
+        native.check(self._L.oc_validate_states(self._handle, count, _ptr(records), _ptr(rejected), self._stream()))
+        return int(rejected.item())
 
     def import_states_checked(self, records, first=0) -> int:
         """Device-to-device import with a per-record validity check; returns the number of rejected (not copied) records."""

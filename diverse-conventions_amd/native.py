@@ -35,7 +35,7 @@ SYMBOLS = [
     "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
     "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
-    "oc_import_states", "oc_import_states_checked", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_set_cu_budget",
+    "oc_import_states", "oc_import_states_checked", "oc_validate_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_set_cu_budget",
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
     "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_cus", "oc_policy_forward_multi", "oc_policy_plan_tiles_multi", "oc_group_policy_rollout_multi", "oc_policy_uniform", "oc_policy_rollout",
     "oc_cu_partition_create", "oc_cu_partition_destroy", "oc_group_policy_rollout",
@@ -142,6 +142,7 @@ def lib():
     L.oc_export_states.argtypes = [vp, i64, i64, vp, vp]
     L.oc_import_states.argtypes = [vp, i64, i64, vp, vp]
     L.oc_import_states_checked.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.oc_validate_states.argtypes = [vp, i64, vp, vp, vp]
     L.oc_num_kitchens.argtypes = [vp]
     L.oc_num_kitchens.restype = i64
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]

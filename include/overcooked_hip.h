@@ -21,7 +21,7 @@
  *   - P = 2 players is the tuned path (the reference's training scripts and its dish-usefulness rule are 2-player): C = 5P+10
  *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
  *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a plain, separate kernel pair with the same buffers and
- *     semantics, C = 5P+10 channels; oc_rollout_fused, oc_encode_trajectory, oc_import_states_checked, groups and the fused
+ *     semantics, C = 5P+10 channels; oc_rollout_fused, oc_encode_trajectory, groups and the fused
  *     policy kernel are 2-player only and return OC_ERR_UNSUPPORTED for them.  S = width*height <= 255 tiles.
  *
  * Tensor layouts (identical in meaning to the reference's exported tensors)
@@ -187,6 +187,10 @@ int oc_import_states(oc_engine *e, int64_t first, int64_t count, const void *d_s
  * 0..4 on tiles and in hands -- everything the kernels index with): records that fail are NOT copied and are counted in
  * *d_rejected (device int32, zeroed by the call).  Checkpoint reload of a whole engine without a host pass. */
 int oc_import_states_checked(oc_engine *e, int64_t first, int64_t count, const void *d_src, int32_t *d_rejected, void *stream);
+/* The check alone: *d_rejected = number of the `count` records at d_src that oc_import_states_checked would refuse; the engine's
+ * kitchens are not touched.  An all-or-nothing reload is this call, a read of the count, and oc_import_states when it is zero.
+ * Both calls take any player count (records in the engine's own format). */
+int oc_validate_states(oc_engine *e, int64_t count, const void *d_src, int32_t *d_rejected, void *stream);
 
 /* ---- runner-side ops ---------------------------------------------------------------
  * Generalised advantage estimation over a whole trajectory batch in one launch; replaces the GAE branches

@@ -19,7 +19,7 @@ def test_bench_two_ranks_one_json_line(clean_launcher):
     assert j1["n_gpus"] == 1 and j1["scaling"] == "weak" and j1["roofline"]["bound"] == "hbm"
     two = clean_launcher.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "300", "--warmup", "50"],
-                             env={"OC_BENCH_DEVICE": "0", "OC_BENCH_BACKEND": "gloo"}, timeout=500)
+                             env={"OC_BENCH_DEVICE": "0", "OC_BENCH_BACKEND": "gloo", "OC_BENCH_EXCHANGE_T": "12"}, timeout=500)
     assert two["rc"] == 0, two["stderr"][-2000:]
     lines2 = [ln for ln in two["stdout"].splitlines() if ln.startswith("{")]
     assert len(lines2) == 1, "rank 0 prints exactly one JSON line"
@@ -32,7 +32,17 @@ def test_bench_two_ranks_one_json_line(clean_launcher):
     assert abs(j2["value"] - 2 * 65536 * 2 * 300 / (j2["ms_per_step"] * 300 / 1e3)) < 1e-3 * j2["value"]
     # the strong-scaling secondary: config 4's split is 65 536 / world kitchens per GPU
     assert j1["config4_split"]["kitchens_per_gpu"] == 65536 and j2["config4_split"]["kitchens_per_gpu"] == 32768
-    assert "cpu_baseline" not in j2 and "hbm_proper" in j2
+    assert "cpu_baseline" not in j2 and "hbm_proper" in j2 and "exchange" not in j1
+    # the exchange leg: config 4's compact trajectory through the one all-gather + featurize_all, both ranks' blocks checked
+    # against the checksums their owners took (gloo moves host buffers here: the test hook says so in the record)
+    ex = j2["exchange"]
+    assert ex["checked"] is True and ex["steps"] == 12 and ex["kitchens_per_gpu"] == 32768 and ex["collectives_per_update"] == 1
+    assert ex["rccl"]["world"] == 2 and ex["rccl"]["backend"] == "gloo" and [d["rank"] for d in ex["rccl"]["devices"]] == [0, 1]
+    assert ex["exchange_ms"] > 0 and ex["refeaturize_ms"] > 0 and ex["GBps_per_gpu_sent"] > 0 and ex["update_amortised_value"] > 0
+    assert abs(ex["MB_sent_per_gpu"] - 12 * 32768 * (208 + 8 + 4 + 4) / 1e6) < 0.01
+    # secondaries run their own fixed counts whatever --steps says
+    assert j2["config4_split"]["steps"] == 1000 and j2["fused_rollout"]["steps"] == 1000 and j2["hbm_proper"]["steps"] == 960
+    assert "roofline_hbm_proper" in j2 and j2["roofline_hbm_proper"]["bound"] == "hbm"
 
 
 def test_rccl_branch_runs_with_one_rank(clean_launcher):
@@ -45,6 +55,12 @@ def test_rccl_branch_runs_with_one_rank(clean_launcher):
     assert b["rc"] == 0, b["stderr"][-2000:]
     j = json.loads([ln for ln in b["stdout"].splitlines() if ln.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["value"] > 1e9
+    # the exchange leg as a real RCCL call on device buffers, full size (65 536 kitchens x 200 steps), checked
+    ex = j["exchange"]
+    assert ex["checked"] is True and ex["steps"] == 200 and ex["kitchens_per_gpu"] == 65536
+    assert ex["rccl"]["backend"] == "nccl" and ex["rccl"]["world"] == 1 and ex["rccl"]["transport"] == "device buffers"
+    assert len(ex["rccl"]["devices"]) == 1 and ex["rccl"]["devices"][0]["device_index"] == 0 and ex["rccl"]["version"]
+    assert ex["exchange_ms"] > 0 and ex["refeaturize_ms"] > 0 and 0 < ex["update_amortised_value"] < j["config4_split"]["value"]
     r = run(["tests/_rccl_single_rank.py"], {}, 29545)
     assert r["rc"] == 0, r["stderr"][-2000:]
     out = json.loads([ln for ln in r["stdout"].splitlines() if ln.startswith("{")][0])

@@ -288,6 +288,44 @@ def test_time_major_steps_of_a_large_small_grid_batch_use_their_own_geometry(lay
     eng.close()
 
 
+@pytest.mark.parametrize("layout", ["unident_s", "random1"])
+def test_benched_shapes_sampled_parity_in_place_and_time_major(layout, layout_params):
+    """The shapes bench.py times beyond the headline, at their full size: asymmetric_advantages x 65 536 (`config4_split` at one GPU)
+    and coordination_ring x 65 536, stepped in place, into time-major slots (the fresh-destination module with its own geometry
+    where there is one) and in place again.  Launch geometry is chosen from the kitchen count, so parity at 8184 kitchens says
+    nothing about this size: (1) 512 sampled kitchens with their own guided streams against the oracle at every step;
+    (2) replication: every kitchen outside the sample gets kitchen 0's stream and must stay identical to it."""
+    params = layout_params[layout]
+    n, T = 65536, 8
+    rng = np.random.default_rng(31)
+    sample = np.sort(rng.choice(np.arange(1, n), size=512, replace=False))
+    own = _mixed_actions(layout, 3 * T, 512, seed=5)
+    lead = _mixed_actions(layout, 3 * T, 1, seed=6)
+    acts = np.repeat(lead, n, axis=2)
+    acts[:, :, sample] = own
+    dacts = torch.from_numpy(acts).cuda()
+    others = np.setdiff1d(np.arange(n), sample)
+    eng = _engine(params, n)
+    ora = oracle.OracleVecEnv(params, 512)
+    slots = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    t = 0
+    for phase in ("in place", "time major", "in place"):
+        if phase == "time major":
+            eng.rollout(dacts[t:t + T], T, obs=slots, reward=rew, done=done)
+        for i in range(T):
+            oobs, orew, odone = ora.step(own[t + i])
+            got, grew, gdone = (slots[i], rew[i], done[i]) if phase == "time major" else eng.step(dacts[t + i])
+            assert np.array_equal(got[:, sample].cpu().numpy(), oobs), (phase, i)
+            assert np.array_equal(grew[:, sample].cpu().numpy(), orew) and np.array_equal(gdone[sample].cpu().numpy(), odone)
+            rest = got[:, others]
+            assert bool((rest == rest[:, :1]).all()), (phase, i, "replication")
+            assert bool((grew[:, others] == grew[:, others[:1]]).all())
+        t += T
+    eng.close()
+
+
 def test_full_size_properties(layout_params):
     """65 536 kitchens (BASELINE.json's size): size-independent checks.
     (1) replication: kitchens fed identical action streams stay identical to kitchen 0;
@@ -461,8 +499,8 @@ def test_env_checkpoint_roundtrip(layout_params, tmp_path):
     other = _engine(layout_params["simple"], n)
     with pytest.raises(ValueError):
         other.load_state_dict(a.state_dict())
-    # corrupted checkpoints are refused on the device (oc_import_states_checked): the damaged records are counted and not
-    # loaded, every other record is
+    # corrupted checkpoints are refused on the device, all or nothing: a validating pass that writes nothing
+    # (oc_validate_states) counts the damaged records, and the engine keeps the state it had
     from diverse_conventions_amd.native import OvercookedNativeError
     sd = a.state_dict()
     good = sd["records"].clone()
@@ -472,9 +510,13 @@ def test_env_checkpoint_roundtrip(layout_params, tmp_path):
     sd["records"][200, 3] = 9                      # object code 9 on a tile
     sd["records"][201, S + 1] = 77                 # ... and in a hand
     c = _engine(params, n)
+    c.rollout(acts, 5)
     before = c.export_states().clone()
     with pytest.raises(OvercookedNativeError, match="4 checkpoint record"):
         c.load_state_dict(sd)
+    assert torch.equal(c.export_states(), before)              # nothing of the bad checkpoint was loaded
+    # the record-by-record import (oc_import_states_checked) skips exactly the damaged ones
+    assert c.import_states_checked(sd["records"].cuda().to(torch.int32)) == 4
     after = c.export_states().cpu()
     bad = [5, 9, 200, 201]
     keep = np.setdiff1d(np.arange(n), bad)

@@ -111,3 +111,19 @@ def test_vector_observation_defaults():
     s = torch.ones(3, 2)
     v = VectorObservation(torch.ones(3, dtype=torch.bool), o, s, torch.ones(3, 6, dtype=torch.bool))
     assert v.state is s and v.action_mask.shape == (3, 6)
+
+
+def test_bench_refuses_two_ranks_on_one_device():
+    """bench.py's exchange leg ends the run when two ranks report the same GPU (the multi-GPU contract is one rank per GPU),
+    unless the OC_BENCH_DEVICE test hook pinned them there."""
+    import bench
+    a = {"rank": 0, "device_index": 0, "uuid": "GPU-aa"}
+    b = {"rank": 1, "device_index": 1, "uuid": "GPU-bb"}
+    assert bench.check_distinct_devices([a, b]) == 2
+    assert bench.check_distinct_devices([dict(a, uuid=None), dict(b, uuid=None)]) == 2
+    with pytest.raises(SystemExit, match="one rank per GPU"):
+        bench.check_distinct_devices([a, dict(b, uuid="GPU-aa")])
+    with pytest.raises(SystemExit, match="one rank per GPU"):
+        bench.check_distinct_devices([dict(a, uuid=None), dict(b, uuid=None, device_index=0)])
+    assert bench.check_distinct_devices([a, dict(b, uuid="GPU-aa")], allow_shared=True) == 1
+    assert bench.algorithmic_bytes(20) == 1012 and bench.algorithmic_bytes(45) == 2212

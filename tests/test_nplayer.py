@@ -73,7 +73,13 @@ def test_hip_vs_oracle_nplayer_batch(case):
     for x, y in zip(eng.get_state(), ora.get_state()):
         assert np.array_equal(x, y)
     assert total > 0 and int(ora.timestep[0]) == T - 400
-    eng.close()
+    # checkpoint reload for this player count (state_dict -> load_state_dict through the device-side validating pass)
+    twin = OvercookedEngine(params, n, 0)
+    twin.load_state_dict(eng.state_dict())
+    assert torch.equal(twin.obs, eng.observe())
+    eng.step(dacts[0]); twin.step(dacts[0])
+    assert torch.equal(twin.obs, eng.obs) and torch.equal(twin.export_states(), eng.export_states())
+    eng.close(); twin.close()
 
 
 def test_four_player_drop_in_env_and_buffers():
@@ -123,6 +129,22 @@ def test_four_player_drop_in_env_and_buffers():
         eng.rollout_fused(3, seed=1)
     with pytest.raises(OvercookedNativeError, match="2-player"):
         EngineGroup([eng, other])
-    with pytest.raises(OvercookedNativeError, match="2-player"):
-        eng.import_states_checked(eng.export_states())
-    eng.close(); other.close()
+    # checkpoint reload with other player counts: the device-side check knows the N-player record, a damaged checkpoint is
+    # refused whole and a good one continues bit-exactly
+    sd = eng.state_dict()
+    fresh = OvercookedEngine(params, n, 0)
+    fresh.load_state_dict(sd)
+    assert torch.equal(fresh.export_states(), eng.export_states()) and torch.equal(fresh.obs, eng.observe())
+    a5 = dacts[5:9, :, :, 0].to(torch.int32).contiguous()
+    eng.rollout(a5, 4); fresh.rollout(a5, 4)
+    assert torch.equal(fresh.obs, eng.obs) and torch.equal(fresh.export_states(), eng.export_states())
+    bad = eng.state_dict()
+    S, P = params["width"] * params["height"], params["num_players"]
+    bad["records"][3, S + P - 1] = 0                                  # the last player on tile 0: a wall
+    bad["records"][7, S + 2 * P - 1] = 9                              # object code 9 in the last player's hands
+    before = fresh.export_states().clone()
+    with pytest.raises(OvercookedNativeError, match="2 checkpoint record"):
+        fresh.load_state_dict(bad)
+    assert torch.equal(fresh.export_states(), before)
+    assert fresh.import_states_checked(bad["records"].cuda().to(torch.int32)) == 2
+    eng.close(); other.close(); fresh.close()
