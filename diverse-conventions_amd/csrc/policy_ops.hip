@@ -45,7 +45,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "overcooked_hip.h"
+#include "overcooked_ops.h"
+#include "overcooked_experiments.h"
+#include "overcooked_debug.h"
 #include "oc_internal.h"
 #include "policy_pack.h"
 
@@ -989,8 +991,8 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
                       float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                       const int32_t *d_row_select, void *stream) {
-    return oc_policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode,
-                                 seed, counter, d_counter, d_row_select, 0, stream);
+    return oc_exp_policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode,
+                                     seed, counter, d_counter, d_row_select, 0, stream);
 }
 
 }  // extern "C"
@@ -1094,7 +1096,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
             return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot query the CU count");
         cus_of[dev] = v;
     }
-    // the launch is sized for the CUs its stream may use: the whole device, or a CU-masked stream's share (oc_cu_partition_create)
+    // the launch is sized for the CUs its stream may use: the whole device, or a CU-masked stream's share (oc_exp_cu_partition_create)
     const int n_cus = cu_budget > 0 ? std::min<int>(cu_budget, cus_of[dev]) : cus_of[dev];
     // A table of at least half as many tiles as CUs is taken as planned (oc_policy_plan_tiles balances one per CU):
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
@@ -1116,10 +1118,10 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
 
 extern "C" {
 
-int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
-                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
-                          const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                              const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                              float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                              const int32_t *d_row_select, int32_t cu_budget, void *stream) {
     if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
     if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_tiles NULL or not 16-byte aligned");
@@ -1192,16 +1194,16 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
     return OC_OK;
 }
 
-int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus) {
-    if (!shares || !out_streams || n < 1 || n > 64) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_cu_partition_create: 1..64 streams");
+int oc_exp_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus) {
+    if (!shares || !out_streams || n < 1 || n > 64) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_exp_cu_partition_create: 1..64 streams");
     const OcDeviceScope on_device(device_id);
-    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: cannot make device %d current", device_id);
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_exp_cu_partition_create: cannot make device %d current", device_id);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < n || cus > 1024)
-        return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: %d CUs cannot be shared out over %d streams", cus, n);
+        return oc_internal_fail(OC_ERR_HIP, "oc_exp_cu_partition_create: %d CUs cannot be shared out over %d streams", cus, n);
     double total = 0;
     for (int i = 0; i < n; ++i) {
-        if (!(shares[i] > 0.f)) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_cu_partition_create: shares must be positive");
+        if (!(shares[i] > 0.f)) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_exp_cu_partition_create: shares must be positive");
         total += shares[i];
     }
     // CUs per stream: proportional, at least one, largest remainders first
@@ -1240,7 +1242,7 @@ int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void *
         const hipError_t e = hipExtStreamCreateWithCUMask(&st, static_cast<uint32_t>(mask[i].size()), mask[i].data());
         if (e != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipStreamDestroy(static_cast<hipStream_t>(out_streams[j]));
-            return oc_internal_fail(OC_ERR_HIP, "oc_cu_partition_create: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+            return oc_internal_fail(OC_ERR_HIP, "oc_exp_cu_partition_create: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
         }
         out_streams[i] = st;
         if (out_cus) out_cus[i] = want[i];
@@ -1248,7 +1250,7 @@ int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void *
     return OC_OK;
 }
 
-int oc_cu_partition_destroy(void *const *streams, int32_t n) {
+int oc_exp_cu_partition_destroy(void *const *streams, int32_t n) {
     if (!streams) return OC_OK;
     for (int i = 0; i < n; ++i)
         if (streams[i]) {
@@ -1258,8 +1260,13 @@ int oc_cu_partition_destroy(void *const *streams, int32_t n) {
     return OC_OK;
 }
 
-int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets, int64_t T,
-                            int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
+int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, int64_t T, int in_place, int sample_mode, uint32_t seed,
+                            uint32_t counter0, void *stream) {
+    return oc_exp_group_policy_rollout_streams(g, slots, nullptr, nullptr, T, in_place, sample_mode, seed, counter0, stream);
+}
+
+int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
+                                        int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
     const int n = oc_group_size(g);
     if (n < 1 || !slots || T < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL group / slots or negative T");
     std::vector<oc_engine *> eng(n);
@@ -1283,7 +1290,7 @@ int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void
     auto policy = [&](int i, int64_t t, hipStream_t st, int budget) {
         const oc_group_policy_slot &s = slots[i];
         const int64_t k = in_place ? 0 : t;
-        return oc_policy_forward_cus(s.shape, s.d_packed, s.n_nets, s.d_obs + k * slot_bytes[i], rows[i], s.d_tiles, s.n_tiles,
+        return oc_exp_policy_forward_cus(s.shape, s.d_packed, s.n_nets, s.d_obs + k * slot_bytes[i], rows[i], s.d_tiles, s.n_tiles,
                                      s.d_values ? s.d_values + k * rows[i] : nullptr, s.d_actions + k * rows[i],
                                      s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr, nullptr, sample_mode,
                                      seed + static_cast<uint32_t>(i) * 0x9E3779B9u, counter0 + static_cast<uint32_t>(t), nullptr, nullptr, budget, st);
@@ -1384,7 +1391,7 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
     return OC_OK;
 }
 
-/* Diagnostics, deliberately not in the public header: per-wavefront phase stamps of the following launches
+/* Diagnostics (overcooked_debug.h): per-wavefront phase stamps of the following launches
  * (tools/trace_policy.py).  enable: allocate and zero; otherwise copy [n_waves][16] stamps out and free. */
 int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves) {
     const size_t cap = 4096 * 4 * 32 * sizeof(unsigned long long);

@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 
-#include "overcooked_hip.h"
+#include "overcooked_ops.h"
 #include "oc_internal.h"
 
 // Build with -ffp-contract=off (native.build does): __fadd_rn & co. are plain operators in HIP, and an FMA

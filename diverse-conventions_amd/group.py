@@ -12,6 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import native
+from .fused_policy import PolicyPlan
 from .engine import OvercookedEngine
 
 _vp = ctypes.c_void_p
@@ -116,30 +117,22 @@ class GroupPairedRollout:
     this as five simulators and 5 x 2(2k+1) sequential `get_actions` calls per joint step (train/env_utils.py:26,
     train/XD/xd_player.py:190-207).  Kitchens of different engines never interact, so the engines need not march in step:
 
-    partition="auto" (default): "one_launch".
-    partition="streams": every engine runs its whole rollout -- policy launch + its own env launch per step -- on its
-        own stream, side by side with the others, no synchronisation between engines: one fork, one join per call.
-        Config 3's shape (8 conventions, 15 segments, 5 x 8190 kitchens): 128 us per joint step, 176 us with critics; config 5's
-        (32 conventions, 63 segments, critics): 202 us (profiles/r02_bench_group_policies.log).
-    partition=False: everything on the current stream -- the policy launches one after the other, then ONE env launch for all
-        engines (`oc_group_step`): 144 / 229 us; the env launch saved is worth less than the overlap lost.
-    partition="cus": as "streams" but on CU-masked streams whose shares follow each layout's policy work
-        (`oc_cu_partition_create`).  Measured SLOWER (328 us): the masks do what they say (k bits -> k CUs, linear throughput,
-        profiles/r02_probe_cu_mask.log; two isolated launches side by side on half-device streams take 49.6 us against 91 us in a
-        row), but these policy launches already scale with the CUs they get, so a fixed split only adds fragmentation.
-    partition="one_launch": everything on the current stream with TWO launches per joint step -- one policy launch over all
+    partition="one_launch" (= "auto", the default): TWO launches per joint step on the current stream -- one policy launch over all
         engines' rows (`oc_policy_forward_multi`: one tile table balanced by block cost; per-layout launches cannot share a CU,
-        so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape 95 us
-        per joint step, 155 us with critics; config 5's 191 us (its 130-kitchen segments run as "wave tiles": one-wavefront
-        workgroups that keep their whole network in L2 / registers, four different networks per CU).
-    Results are identical in all modes.
+        so at 8192 kitchens per layout they leave half the SIMDs idle) and one env launch (`oc_group_step`): config 3's shape
+        (8 conventions, 15 segments, 5 x 8190 kitchens) 95 us per joint step, 155 us with critics; config 5's (32 conventions, 63
+        segments, critics) 191 us -- its 130-kitchen segments run as "wave tiles": one-wavefront workgroups that keep their whole
+        network in L2 / registers, four different networks per CU (profiles/r02_bench_group_policies.log).
+    partition=False: the engines' policy launches one after the other, then ONE env launch for all engines: 144 / 229 us.
+    Results are identical in both modes.  (Every engine on its own stream -- 128 / 176 us -- and on CU-masked streams -- 328 us --
+    were measured and not adopted; they live in tools/exp_group_streams.py over include/overcooked_experiments.h.)
 
     nets[i]: PackedNetworks of engine i's grid; threads[i] kitchens per pairing segment (engine i holds threads[i] * (2k+1));
     critic_nets[i][side][g] as in FusedPairedRollout (or None)."""
 
     def __init__(self, group: EngineGroup, nets, threads, n_conventions: int, critic_nets=None, deterministic: bool = False, seed: int = 0,
                  partition="auto"):
-        from .fused_policy import TILE_ACT, PolicyPlan, _shape
+        from .fused_policy import TILE_ACT, _shape
         from .policy import segment_policy_indices
         from .sharding import pairing_segments
         self.group, self.nets, self.deterministic, self.seed = group, list(nets), deterministic, int(seed)
@@ -165,35 +158,19 @@ class GroupPairedRollout:
         self.has_critics = [critic_nets is not None and critic_nets[i] is not None for i in range(n_eng)]
         L = native.lib()
         self._L = L
-        self._streams = (_vp * n_eng)()
-        self._cus = (ctypes.c_int32 * n_eng)()
-        if partition is True:
-            partition = "cus"
         if partition == "auto":
             # one policy launch over all grids + one env launch: 95 / 155 us per joint step against 128 / 176 on five streams
             # (config 3's shape), 191 against 202 us with config 5's short segments, which the planner runs as wave tiles
             partition = "one_launch"
-        if partition not in (False, None, "streams", "cus", "one_launch"):
-            raise ValueError("partition must be 'auto', False, 'streams' (one ordinary stream per engine), 'cus' (CU-masked streams) or 'one_launch'")
-        self.partition = partition if (partition and (n_eng > 1 or partition == "one_launch")) else False
+        if partition not in (False, None, "one_launch"):
+            raise ValueError("partition must be 'auto', 'one_launch' or False (the per-engine-stream experiments: tools/exp_group_streams.py)")
+        self.partition = partition or False
         self._one_launch = self.partition == "one_launch"
         if self._one_launch:
             from .fused_policy import MultiPolicyPlan
-            self.partition = False                                        # stream handling as the single-stream mode
             self.multi_plan = MultiPolicyPlan(self.nets, [2 * e.num_kitchens for e in group.engines], rows_all)
-        self._partitioned = self.partition == "cus"                       # CU budgets apply
-        self._side_streams = bool(self.partition)
-        self._torch_streams = None
-        if self.partition == "cus":
-            shares = (ctypes.c_float * n_eng)(*[w / sum(work) for w in work])
-            native.check(L.oc_cu_partition_create(group.device.index or 0, shares, n_eng, self._streams, self._cus))
-        elif self.partition == "streams":
-            self._torch_streams = [torch.cuda.Stream(group.device) for _ in range(n_eng)]
-            for i, st in enumerate(self._torch_streams):
-                self._streams[i] = st.cuda_stream
-        cus_total = torch.cuda.get_device_properties(group.device).multi_processor_count
-        self.plans = [PolicyPlan(nt, 2 * e.num_kitchens, rows, rows_per_tile=-(int(self._cus[i]) if self._partitioned else cus_total))
-                      for i, (e, nt, rows) in enumerate(zip(group.engines, self.nets, rows_all))]
+        self._rows_all, self._work = rows_all, work
+        self.plans = self._make_plans(rows_all)
         dev = group.device
         self.actions = [torch.zeros((2, e.num_kitchens), dtype=torch.int32, device=dev) for e in group.engines]
         self.logp = [torch.zeros((2, e.num_kitchens), dtype=torch.float32, device=dev) for e in group.engines]
@@ -202,12 +179,11 @@ class GroupPairedRollout:
         self._shapes = [_shape(nt.W, nt.H, 6, nt.digits) for nt in self.nets]
         self.steps_done = 0
 
-    @property
-    def cu_shares(self):
-        """CUs given to each engine's policy stream (whole device each when not partitioned)."""
-        return [int(c) for c in self._cus] if self._partitioned else None
+    def _make_plans(self, rows_all):
+        cus_total = torch.cuda.get_device_properties(self.group.device).multi_processor_count
+        return [PolicyPlan(nt, 2 * e.num_kitchens, rows, rows_per_tile=-cus_total) for e, nt, rows in zip(self.group.engines, self.nets, rows_all)]
 
-    def _run(self, T, in_place, obs, actions, logp, values, reward, done):
+    def _slots(self, obs, actions, logp, values, reward, done):
         p = lambda t: _vp(t.data_ptr()) if t is not None else None
         slots = (native.OcGroupPolicySlot * len(self.group))()
         for i, (nt, plan) in enumerate(zip(self.nets, self.plans)):
@@ -216,17 +192,18 @@ class GroupPairedRollout:
             s.d_packed, s.n_nets, s.d_tiles, s.n_tiles = p(nt.image), nt.n_nets, p(plan.tiles), plan.n_tiles
             s.d_obs, s.d_actions, s.d_action_logp, s.d_values = p(obs[i]), p(actions[i]), p(logp[i]), p(values[i])
             s.d_reward, s.d_done = p(reward[i]), p(done[i])
+        return slots
+
+    def _run(self, T, in_place, obs, actions, logp, values, reward, done):
+        slots = self._slots(obs, actions, logp, values, reward, done)
+        sample, seed, c0 = 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF
         if self._one_launch:
             native.check(self._L.oc_group_policy_rollout_multi(
                 self.group._handle, slots, _vp(self.multi_plan.tiles.data_ptr()), self.multi_plan.n_tiles, self.multi_plan.tiles_per_workgroup,
-                self.multi_plan.waves_per_workgroup, int(T),
-                1 if in_place else 0,
-                0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
-            self.steps_done += int(T)
-            return
-        native.check(self._L.oc_group_policy_rollout(
-            self.group._handle, slots, self._streams if self._side_streams else None, self._cus if self._partitioned else None, int(T),
-            1 if in_place else 0, 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, self.group._stream()))
+                self.multi_plan.waves_per_workgroup, int(T), 1 if in_place else 0, sample, seed, c0, self.group._stream()))
+        else:
+            native.check(self._L.oc_group_policy_rollout(self.group._handle, slots, int(T), 1 if in_place else 0, sample, seed, c0,
+                                                         self.group._stream()))
         self.steps_done += int(T)
 
     def step(self, steps: int = 1):
@@ -251,13 +228,4 @@ class GroupPairedRollout:
         return trajs
 
     def close(self):
-        if self.partition == "cus" and self._streams is not None:
-            torch.cuda.synchronize(self.group.device)
-            self._L.oc_cu_partition_destroy(self._streams, len(self.group))
-            self._streams = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        pass

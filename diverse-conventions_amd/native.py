@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI in include/overcooked_hip.h (library: csrc/liboc_hip.so).
+"""ctypes binding of the C ABI in include/overcooked_hip.h + overcooked_ops.h (library: csrc/liboc_hip.so).
 
 The library is the product: if it is missing or cannot be loaded this module raises -- there is no
 Python or CPU fallback for the hot path (the CPU oracle under oracle/ is test infrastructure).
@@ -29,18 +29,27 @@ OC_OK = 0
 OC_ACT_I32, OC_ACT_I64 = 0, 1
 STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", -3: "OC_ERR_HIP", -4: "OC_ERR_NO_DEVICE"}
 
-# every symbol include/overcooked_hip.h declares (tests/test_abi.py checks the header against this)
-SYMBOLS = [
+# every symbol the public headers declare (tests/test_abi.py checks header text, these lists and the library's export table
+# against each other): include/overcooked_hip.h -- the environment: engines, groups, state ...
+SYMBOLS_ENV = [
     "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
     "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
     "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
-    "oc_import_states", "oc_import_states_checked", "oc_validate_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_set_cu_budget",
-    "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
-    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_cus", "oc_policy_forward_multi", "oc_policy_plan_tiles_multi", "oc_group_policy_rollout_multi", "oc_policy_uniform", "oc_policy_rollout",
-    "oc_cu_partition_create", "oc_cu_partition_destroy", "oc_group_policy_rollout",
+    "oc_import_states", "oc_import_states_checked", "oc_validate_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
+# ... include/overcooked_ops.h -- policy inference, rollouts with the policies in the loop, GAE, minibatch gathers
+SYMBOLS_OPS = [
+    "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
+    "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_multi",
+    "oc_policy_plan_tiles_multi", "oc_group_policy_rollout_multi", "oc_policy_uniform", "oc_policy_rollout", "oc_group_policy_rollout",
+]
+SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
+# include/overcooked_experiments.h (measured and not adopted; tools/ only) and include/overcooked_debug.h (diagnostics)
+SYMBOLS_EXPERIMENTS = ["oc_exp_cu_partition_create", "oc_exp_cu_partition_destroy", "oc_exp_policy_forward_cus", "oc_exp_set_cu_budget",
+                       "oc_exp_group_policy_rollout_streams"]
+SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group", "oc_debug_trace", "oc_policy_debug_trace"]
 
 
 class OcPolicyShape(ctypes.Structure):
@@ -83,8 +92,8 @@ class OvercookedNativeError(RuntimeError):
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
-    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, KERNEL_COMMON, KERNEL_BODY,
-                                                                    os.path.join(INCLUDE, "overcooked_hip.h")])
+    newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, KERNEL_COMMON, KERNEL_BODY] +
+                 [os.path.join(INCLUDE, h) for h in ("overcooked_hip.h", "overcooked_ops.h", "overcooked_experiments.h", "overcooked_debug.h")])
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     # the kernel headers are also embedded as text: oc_create() / oc_group_create() re-compile them with hiprtc
@@ -148,7 +157,7 @@ def lib():
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
     L.oc_device_id.argtypes = [vp]
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
-    L.oc_set_cu_budget.argtypes = [vp, ctypes.c_int32]
+    L.oc_exp_set_cu_budget.argtypes = [vp, ctypes.c_int32]
     fp = ctypes.c_float
     L.oc_gae_returns.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, i32, fp, fp, i32, vp]
     L.oc_advantage_workspace_bytes.argtypes = []
@@ -168,11 +177,14 @@ def lib():
     L.oc_policy_plan_tiles.restype = i64
     L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp]
     L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
-    L.oc_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
-    L.oc_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
-    L.oc_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
-    L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
-                                          u32, u32, vp]
+    L.oc_exp_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
+    L.oc_exp_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
+    L.oc_exp_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
+    L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), i64, i32, i32, u32, u32, vp]
+    L.oc_exp_group_policy_rollout_streams.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
+                                                      u32, u32, vp]
+    L.oc_debug_trace.argtypes = [vp, i32, vp, i64]
+    L.oc_policy_debug_trace.argtypes = [i32, vp, i64]
     L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i32, i64, i32, i32, u32, u32, vp]
     L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, i32, u32, vp, vp]
     L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -200,7 +212,7 @@ def lib():
     L.oc_group_build_info.restype = ctypes.c_char_p
     L.oc_debug_jit_compile_group.argtypes = [ctypes.POINTER(OcLayoutParams), ctypes.POINTER(i64), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, i64]
-    for name in SYMBOLS:
+    for name in SYMBOLS + SYMBOLS_EXPERIMENTS + SYMBOLS_DEBUG:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:          # default restype: int status
             fn.restype = ctypes.c_int

@@ -1,0 +1,30 @@
+/*
+ * overcooked_debug.h -- diagnostics exported by the library for the CPU test-suite and the profiling tools; not part of the
+ * drop-in boundary.
+ */
+#ifndef OVERCOOKED_DEBUG_H
+#define OVERCOOKED_DEBUG_H
+
+#include "overcooked_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Compile-only check of the per-engine (hiprtc) kernel build, no GPU needed: OC_OK and the code object size, or the compiler
+ * log (tests/test_abi.py, __graft_entry__.build()). */
+int oc_debug_jit_compile(const oc_layout_params *p, int64_t n_kitchens, const char *arch, int64_t *code_bytes, char *log_out, int64_t log_cap);
+/* The same for a group module (one launch over n_engines engines): plans the geometry for `num_cus` CUs and compiles.
+ * plan_out (optional, 2 * n_engines ints): kitchens per wavefront group and blocks of every engine. */
+int oc_debug_jit_compile_group(const oc_layout_params *params, const int64_t *n_kitchens, int32_t n_engines, int32_t num_cus, const char *arch,
+                               int64_t *code_bytes, int32_t *plan_out, char *log_out, int64_t log_cap);
+/* Per-wavefront phase stamps (s_memrealtime) of the step kernel's next launches (tools/trace_phases.py).  enable != 0: allocate
+ * and zero the trace buffer; 0: copy [max_waves][16] stamps to host_out (may be NULL) and free it. */
+int oc_debug_trace(oc_engine *e, int enable, unsigned long long *host_out, int64_t max_waves);
+/* The same for the fused policy kernel (tools/trace_policy.py): [n_waves][32] stamps. */
+int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVERCOOKED_DEBUG_H */

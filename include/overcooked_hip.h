@@ -10,6 +10,11 @@
  * supplied by the caller -- torch tensors on the Python side), plus state import/export for tests,
  * checkpoints and trajectory exchange.
  *
+ * This header is the environment itself: engines, groups of engines, state.  What sits on either side of the env step in
+ * the training loop (policy inference on the matrix cores, GAE, minibatch gathers, rollouts with the policies in the loop)
+ * is declared in overcooked_ops.h; measured-and-rejected experiments in overcooked_experiments.h; diagnostics in
+ * overcooked_debug.h.  All four are served by the one library.
+ *
  * Conventions
  *   - every entry point returns OC_OK (0) or a negative oc_status; oc_last_error() gives the text
  *     (thread-local).  No exceptions cross the boundary, nothing aborts the process.
@@ -55,7 +60,7 @@ extern "C" {
 #define OC_MAX_TILES 255
 #define OC_MAX_PLAYERS 4
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 4
+#define OC_ABI_VERSION 5
 
 typedef enum {
     OC_OK = 0,
@@ -192,203 +197,6 @@ int oc_import_states_checked(oc_engine *e, int64_t first, int64_t count, const v
  * Both calls take any player count (records in the engine's own format). */
 int oc_validate_states(oc_engine *e, int64_t count, const void *d_src, int32_t *d_rejected, void *stream);
 
-/* ---- runner-side ops ---------------------------------------------------------------
- * Generalised advantage estimation over a whole trajectory batch in one launch; replaces the GAE branches
- * of SharedReplayBuffer.compute_returns (train/MAPPO/utils/shared_buffer.py:248-304) and the advantage
- * subtraction of train/MAPPO/r_mappo.py:174-177.  All tensors f32, time-major, M = envs * agents:
- *   rewards [T][M], value_preds [T+1][M] (row T = next_value), masks [T+1][M], bad_masks [T+1][M] (only read
- *   with proper_time_limits), returns [T+1][M] (rows 0..T-1 written), advantages [T][M] or NULL.
- * denormalize != 0: value_preds are ValueNorm/PopArt-normalised, v*vn_std + vn_mean is applied as in
- * valuenorm.py:74-83.  Bit-identical to the reference's torch expressions (same f32 op order, no FMA). */
-int oc_gae_returns(const float *d_rewards, const float *d_value_preds, const float *d_masks, const float *d_bad_masks,
-                   float *d_returns, float *d_advantages, int64_t T, int64_t M, double gamma, double gae_lambda,
-                   int denormalize, float vn_mean, float vn_std, int proper_time_limits, void *stream);
-
-/* Advantage normalisation of train/XD/xd.py:240-244 (= train/MAPPO/r_mappo.py:177-181) over n f32 elements:
- *   mean = nanmean over entries with active_mask != 0 ; std = unbiased std ; out = (adv - mean) / (std + 1e-5).
- * std_over_active = 0 keeps the reference's behaviour (its `copy != nan` selects every entry, so the std --
- * and every output -- is NaN as soon as one entry is inactive); 1 takes the std of the active entries.
- * d_active_masks may be NULL (all active); d_out may alias d_adv or be NULL (statistics only);
- * d_stats receives {mean, std}; d_workspace holds oc_advantage_workspace_bytes() bytes.  Sums are taken in f64
- * in a fixed order: reproducible run to run, within 1e-6 of torch's f32 reductions. */
-int64_t oc_advantage_workspace_bytes(void);
-int oc_advantage_normalize(const float *d_adv, const float *d_active_masks, int64_t n, int std_over_active, float *d_out,
-                           float *d_stats, void *d_workspace, void *stream);
-
-/* Row gather, dst row i <- src row d_index[i] (NULL index = identity): the data movement of
- * SharedReplayBuffer.feed_forward_generator / partial_ff_generator (shared_buffer.py:331-345, 393-407) and of
- * diaginsert / partinsert (:167-179, :200-212) with the index arithmetic done by the caller on the device.
- * Rows are row_bytes bytes of int8 observations (multiple of 4, <= 5120); dst_dtype 0 copies the bytes,
- * 1 writes f32 (the reference's buffer dtype; cast fused).  Indices outside [0, src_rows) are clamped. */
-int oc_gather_rows(const void *d_src, int64_t src_rows, int32_t row_bytes, const int64_t *d_index, int64_t n_rows, void *d_dst,
-                   int dst_dtype, void *stream);
-/* The scalar side of a minibatch: up to 8 columns of words[c] 4-byte words per row (value_preds, returns, masks,
- * active_masks, actions, action_log_probs, advantages, rnn_states ...) gathered in one launch; source row =
- * d_index[i] * row_mul + row_add -- (1, 0) for feed_forward_generator, (num_agents, agent) for
- * partial_ff_generator.  d_src / d_dst / src_rows / words / d_norm_stats are HOST arrays of n_cols entries;
- * a non-NULL d_norm_stats[c] (device {mean, std} from oc_advantage_normalize) normalises column c on the fly. */
-int oc_gather_columns(int32_t n_cols, const void *const *d_src, const int64_t *src_rows, const int32_t *words, void *const *d_dst,
-                      const float *const *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
-                      void *stream);
-/* Sample records: oc_pack_columns interleaves n_cols (<= 8) one-word columns of n_rows rows into 32-byte records
- * d_packed[n_rows][8] (once per update, streaming); oc_gather_records reads one record per sample -- one 32-byte
- * sector instead of n_cols -- and writes the columns out separately and contiguously (d_dst: HOST array of n_cols
- * device pointers, each [n_rows] words).  Row mapping as oc_gather_columns; norm_col >= 0 normalises that column
- * with d_norm_stats = {mean, std} on the fly, -1 none. */
-int oc_pack_columns(int32_t n_cols, const void *const *d_src, int64_t n_rows, void *d_packed, void *stream);
-int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, void *const *d_dst, int32_t norm_col,
-                      const float *d_norm_stats, const int64_t *d_index, int64_t n_rows, int64_t row_mul, int64_t row_add,
-                      void *stream);
-
-/* ---- fused policy inference on the matrix cores --------------------------------------------
- * One launch evaluates every (row range, network) tile of a rollout step -- all conventions' actors and critics,
- * both sides, every pairing segment -- reading the int8 observations oc_step wrote and writing the int32 actions
- * oc_step reads.  Replaces the per-segment loops over policy.get_actions (train/XD/xd_player.py:190-207,
- * train/partner_agents.py:97-111; rMAPPOPolicy.get_actions = R_Actor.forward + R_Critic.forward,
- * train/MAPPO/r_actor_critic.py:57-76,175-199) for the reference architecture: CNNBase (utils/cnn.py:12-60: conv 3x3
- * valid 20 -> hidden/2, ReLU, flatten, Linear -> hidden, ReLU, Linear -> hidden, ReLU) + one Linear head
- * (6 action logits, utils/act.py + distributions.py:60-80, or 1 value, `v_out`).  hidden_size 64 (train_xp.sh:12);
- * other sizes return OC_ERR_UNSUPPORTED.  Numerics: conv in exact integer arithmetic on `digits` base-128
- * fixed-point weight digits (4: quantisation 2^-28 of each channel's largest weight; the channel's bias rides in the
- * same units), dense layers as f32 x f32 products on the bf16 matrix pipe (both operands split exactly into three bf16
- * pieces, six piece products each, f32 accumulate: what is dropped is below 2^-23 of a product); outputs agree with
- * the reference's f32 forward to ~1e-6 of their magnitude (tools/policy_accuracy.py measures it against float64). */
-typedef struct {
-    int32_t width, height;     /* observation grid; rows are width*height*20 int8, C fastest, W before H */
-    int32_t hidden;            /* reference --hidden_size: 64 */
-    int32_t n_out;             /* head outputs of the network being packed: 1..8 (6 logits / 1 value) */
-    int32_t digits;            /* conv weight digits 1..4 (7, 14, 21, 28 bits) */
-} oc_policy_shape;
-
-#define OC_POLICY_TILE_ACT 1   /* tile flag: actor epilogue (log-softmax, action draw); otherwise raw head outputs */
-#define OC_POLICY_TILE_SELECT(v) ((((v) + 1) & 0xff) << 8)   /* tile flag: write only rows whose d_row_select entry == v (0..254) */
-
-/* Bytes of one packed network (a function of width, height, digits only; multiple of 256). < 0 on error. */
-int64_t oc_policy_packed_bytes(const oc_policy_shape *shape);
-/* Pack one network from the reference's state-dict tensors (f32, contiguous): conv_w [32][20][3][3]
- * (base.cnn.cnn.0.weight), conv_b [32], fc1_w [64][32*(W-2)*(H-2)] (base.cnn.cnn.3), fc1_b, fc2_w [64][64]
- * (base.cnn.cnn.5), fc2_b, head_w [n_out][64] (act.action_out.linear / v_out), head_b.  _host: host pointers,
- * synchronous (tests, C clients); the other: device pointers, stream-ordered (after an optimiser step). */
-int oc_policy_pack_host(const oc_policy_shape *shape, const float *conv_w, const float *conv_b, const float *fc1_w,
-                        const float *fc1_b, const float *fc2_w, const float *fc2_b, const float *head_w, const float *head_b,
-                        void *host_dst);
-int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const float *d_conv_b, const float *d_fc1_w,
-                   const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b, const float *d_head_w,
-                   const float *d_head_b, void *d_dst, void *stream);
-/* Cut segments (row0, rows, network index, flags) into workgroup tiles: host_tiles int32 [capacity][4] = {row0, rows,
- * net, flags}.  rows_per_tile > 0 (a multiple of 32): fixed-size tiles.  rows_per_tile < 0: -rows_per_tile workgroups
- * (pass the CU count) are shared out over the segments in proportion to their rows and every segment is cut into
- * near-equal pieces -- one balanced tile per CU, no workgroup ever changes network.  Returns the tile count
- * (host_tiles may be NULL to ask for it), < 0 on error.  oc_policy_forward runs a table of >= CUs/2 tiles one
- * workgroup per tile, a shorter one by splitting its 32-row blocks evenly over one workgroup per CU.
- * Pairing segments: train/XD/serial.py:27, xd_player.py:76-77,94. */
-int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
-                             int32_t n_segs, int32_t rows_per_tile, int32_t *host_tiles, int64_t capacity);
-/* d_packed: n_nets packed networks of this shape (n_out may differ per network; it is read from each image),
- * d_obs int8 [n_rows][W][H][20], d_tiles int32 [n_tiles][4] on the device.  Tiles without OC_POLICY_TILE_ACT write
- * d_raw[row * n_out + a] (raw head outputs: critic values, or logits); tiles with it write d_actions[row] (int32),
- * d_action_logp[row] and, if non-NULL, d_logp[row * n_out + a] (normalised log-probabilities).  sample_mode 0 =
- * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter + *d_counter, row, a);
- * d_counter (device uint32, may be NULL = 0) lets a captured HIP graph draw fresh actions on every replay.
- * d_row_select (int32 [n_rows], may be NULL): per-row policy mixing -- tiles flagged OC_POLICY_TILE_SELECT(v) write only
- * the rows whose entry equals v, so two networks laid over the same rows fill one output buffer between them (the
- * reference's `mix_mask == i` indexing, train/XD/xd_player.py:287-305, train/partner_agents.py:171-196).
- * Rows and network indices of a bad tile are clamped; any output pointer may be NULL. */
-int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
-                      const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                      float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
-                      const int32_t *d_row_select, void *stream);
-float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
-/* oc_policy_forward sized for a SHARE of the GPU: cu_budget = number of CUs the stream may use (a CU-masked stream from
- * oc_cu_partition_create; 0 = the whole device).  One workgroup per CU of the budget; plan the tile table for it
- * (oc_policy_plan_tiles(..., -cu_budget, ...)). */
-int oc_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
-                          const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                          float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
-                          const int32_t *d_row_select, int32_t cu_budget, void *stream);
-/* One launch over SEVERAL observation tensors of different grids (the layouts of an engine group): every slot is what
- * oc_policy_forward takes for one grid; tiles name their slot with OC_POLICY_TILE_SLOT(i) in the flags.
- * oc_policy_plan_tiles_multi lays the 32-row blocks of all segments out as one sequence and gives every workgroup an equal share
- * of its COST (slot_cost[i]: relative cost of a block of slot i -- (W-2)*(H-2) + 2.5 fits the measured launches), cutting
- * segments at the share boundaries: host_tiles then holds *tiles_per_workgroup entries per workgroup (empty ones as padding),
- * workgroups * *tiles_per_workgroup in all (the return value; host_tiles may be NULL to ask for it).  Five per-layout
- * launches cannot share a CU (each fills its registers and LDS), so at 8192 kitchens per layout they leave half the SIMDs
- * without a block; one balanced table does not.  All slots' networks must use the same number of conv digits; at most 8 slots.
- * *waves_per_workgroup comes back 4, or 1 for tables of short segments (fewer than 12 blocks each on average: "wave tiles" -- the
- * table is then planned for 4 x workgroups one-wavefront workgroups that keep their whole network in L2 / registers, so four
- * different networks run on a CU side by side); pass both numbers on to oc_policy_forward_multi. */
-#define OC_POLICY_TILE_SLOT(i) (((i) & 7) << 16)
-typedef struct {
-    const oc_policy_shape *shape;
-    const void *d_packed;
-    int32_t n_nets;
-    const int8_t *d_obs;
-    int64_t n_rows;
-    float *d_raw;                  /* any output may be NULL */
-    int32_t *d_actions;
-    float *d_action_logp;
-    float *d_logp;
-    const int32_t *d_row_select;
-    uint32_t seed;
-} oc_policy_multi_slot;
-int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_rows, const int32_t *seg_net, const int32_t *seg_flags,
-                                   const int32_t *seg_slot, const float *slot_cost, int32_t n_slots, int32_t n_segs, int32_t workgroups,
-                                   int32_t *host_tiles, int64_t capacity, int32_t *tiles_per_workgroup, int32_t *waves_per_workgroup);
-int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                            int32_t waves_per_workgroup, int sample_mode, uint32_t counter, const uint32_t *d_counter, void *stream);
-/* n HIP streams restricted to disjoint sets of the device's CUs, stream i getting about shares[i] / sum(shares) of them (at
- * least one; every set spread over the whole CU index range).  k mask bits give k CUs and proportional throughput
- * (tools/probes/cu_mask.hip); two isolated policy launches of 8184 asymmetric_advantages kitchens take 49.6 us together on two
- * half-device streams against 91 us one after the other.  For the five-layout rollout a fixed split measured slower than plain
- * streams (see oc_group_policy_rollout), so nothing in the package uses it by default.  out_streams: n hipStream_t (as void*),
- * out_cus (optional): CUs given to each.  Destroy with oc_cu_partition_destroy. */
-int oc_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus);
-int oc_cu_partition_destroy(void *const *streams, int32_t n);
-/* T rollout steps of every engine of a group with the policies in the loop, enqueued from C -- the reference's five-layout
- * training / evaluation loop (BASELINE configs 3 and 5).  Two modes:
- *   policy_streams == NULL: everything on `stream`; per joint step the engines' policy launches one after the other, then
- *     ONE env launch for all of them (oc_group_step);
- *   policy_streams given (ordinary streams, or CU-masked ones with their cu_budgets): kitchens of different engines never
- *     interact, so engine i runs its whole rollout -- per step its policy launch and its own env launch -- on policy_streams[i],
- *     side by side with the others and without any synchronisation between engines; `stream` is forked once at the start and
- *     joined once at the end.  (Joining the streams at every step for a common env launch was measured first: 1.3 ms per joint
- *     step.)  Config 3's shape: 173 us per joint step on five ordinary streams, 186 us on one stream, 423 us on CU-masked ones.
- * slots[i] describes engine i exactly as oc_policy_rollout's arguments do (same buffers, same in_place meaning; the draw counter
- * of step t is counter0 + t, the seed is offset per engine).  Results are identical in both modes. */
-typedef struct {
-    const oc_policy_shape *shape;
-    const void *d_packed;
-    int32_t n_nets;
-    const int32_t *d_tiles;
-    int32_t n_tiles;
-    int8_t *d_obs;
-    int32_t *d_actions;
-    float *d_action_logp;      /* may be NULL */
-    float *d_values;           /* may be NULL */
-    int32_t *d_reward;
-    int32_t *d_done;
-} oc_group_policy_slot;
-int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets, int64_t T,
-                            int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
-/* The same rollout with TWO launches per joint step on one stream: one oc_policy_forward_multi over every engine's rows
- * (d_tiles from oc_policy_plan_tiles_multi, slot i = engine i; the slots' own d_tiles are ignored) and one oc_group_step.
- * Same seeds and counters as oc_group_policy_rollout: identical results. */
-int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
-                                  int32_t waves_per_workgroup, int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
-/* T rollout steps with the policies in the loop, enqueued from C (no host work between launches): per step one
- * oc_policy_forward over the 2N rows of the engine's observation (tiles address rows player * N + kitchen; critic
- * tiles write d_values) and one oc_step.  What XDPlayer.next_step does per step through 2(2k+1) get_actions calls
- * (train/XD/xd_player.py:177-230).  in_place = 0: time-major trajectory -- d_obs int8 [T+1][P][N][W][H][C] with slot 0
- * holding the current observation (oc_observe), d_actions int32 [T][P][N], d_action_logp / d_values f32 [T][P][N] or
- * NULL, d_reward int32 [T][P][N], d_done int32 [T][N]; step t reads slot t and writes slot t+1.  in_place != 0: one
- * slot of each, overwritten every step.  The draw counter of step t is counter0 + t.  d_row_select: NULL, or int32 [T][2N]
- * per-row policy choices of every step (always time-major), as oc_policy_forward takes them for one step: the whole
- * mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) is then one call. */
-int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
-                      int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
-                      float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
-                      const int32_t *d_row_select, void *stream);
-
 /* Introspection */
 int64_t oc_num_kitchens(const oc_engine *e);
 int oc_obs_shape(const oc_engine *e, int64_t shape5[5]);   /* P, N, W, H, C */
@@ -398,10 +206,6 @@ int oc_device_id(const oc_engine *e);
  * kitchens*tiles must be a multiple of 4, so any multiple of 4 works), 64-tile staging passes per flush (1..8), persistent wavefronts per CU (1..32).
  * 0 keeps the current value. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
-
-/* Size the engine's launches for a stream that may only use `cus` of the GPU's CUs (a CU-masked stream from
- * oc_cu_partition_create): the persistent grid becomes waves_per_cu x cus wavefronts.  0 = the whole device (default). */
-int oc_set_cu_budget(oc_engine *e, int32_t cus);
 
 /* Which kernel build serves this engine: "specialised for gfx950..." when the per-engine hiprtc build
  * succeeded at oc_create, otherwise the reason the generic ahead-of-time kernel is in use. */

@@ -10,19 +10,31 @@ from conftest import ROOT
 from diverse_conventions_amd import get_base_layout_params, layout_names, native
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "overcooked_hip.h")).read()
+def header_functions(name):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(oc_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Four headers, one library: the environment (what the reference's bindings.cpp:27-96 binds), the training-loop ops, the
+    measured-and-rejected experiments (tools/ only), diagnostics.  Header text, the binding's lists and the library's dynamic
+    symbol table must agree -- nothing exported that no header declares, nothing declared that is not exported."""
+    import subprocess
     L = native.lib()
-    declared = header_functions()
-    assert sorted(native.SYMBOLS) == declared
+    assert sorted(native.SYMBOLS_ENV) == header_functions("overcooked_hip.h")
+    assert sorted(native.SYMBOLS_OPS) == header_functions("overcooked_ops.h")
+    assert sorted(native.SYMBOLS_EXPERIMENTS) == header_functions("overcooked_experiments.h")
+    assert sorted(native.SYMBOLS_DEBUG) == header_functions("overcooked_debug.h")
+    declared = native.SYMBOLS + native.SYMBOLS_EXPERIMENTS + native.SYMBOLS_DEBUG
     for name in declared:
         assert getattr(L, name) is not None, name
-    assert L.oc_abi_version() == 4
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if re.search(r" [TW] oc_[a-z_0-9]+$", ln) and "oc_internal" not in ln})
+    assert exported == sorted(declared)
+    assert L.oc_abi_version() == 5
+    # the drop-in boundary stays small: no experiment or diagnostic leaks into the two public headers
+    assert not [f for f in native.SYMBOLS if f.startswith(("oc_exp_", "oc_debug_")) or "_cus" in f or "cu_" in f]
 
 
 def test_layout_struct_matches_header():
@@ -100,6 +112,9 @@ def test_plain_c_client_links_and_gets_error_codes(tmp_path):
 #include <stdio.h>
 #include <string.h>
 #include "overcooked_hip.h"
+#include "overcooked_ops.h"
+#include "overcooked_experiments.h"
+#include "overcooked_debug.h"
 int main(void) {
     oc_layout_params p; oc_engine *e = NULL; int rc;
     memset(&p, 0, sizeof p);
@@ -112,4 +127,4 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
-    assert out[0] == "-2" and "players" in out[1] and out[2] == "4" and out[3] == "0"
+    assert out[0] == "-2" and "players" in out[1] and out[2] == "5" and out[3] == "0"

@@ -146,7 +146,7 @@ def config3_policies(n=8192, k=7, T=200, critics=True):
     return out
 
 
-def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"):
+def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="one_launch"):
     """Config 3 / 5 shape with the policies in the loop as 5 + 1 launches per joint step: every layout's fused policy launch side
     by side on CU-masked streams + ONE env launch for the five engines (GroupPairedRollout / oc_group_policy_rollout)."""
     from diverse_conventions_amd import EngineGroup, GroupPairedRollout, PackedNetworks
@@ -167,7 +167,11 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"
         engines.append(OvercookedEngine(params, threads * G, 0))
     grp = EngineGroup(engines)
     cn = [[[k + 1 + g for g in range(G)]] * 2] * 5 if critics else None
-    ro = GroupPairedRollout(grp, nets, threads, k, critic_nets=cn, partition=partition)
+    if partition in ("streams", "cus"):                     # the per-engine-stream experiments (include/overcooked_experiments.h)
+        from exp_group_streams import StreamedGroupPairedRollout
+        ro = StreamedGroupPairedRollout(grp, nets, threads, k, mode=partition, critic_nets=cn)
+    else:
+        ro = GroupPairedRollout(grp, nets, threads, k, critic_nets=cn, partition=partition)
     ro.step(20)
     sec = timed(lambda: ro.step(T))
     kitchens = sum(e.num_kitchens for e in engines)
@@ -178,7 +182,7 @@ def config3_group_policies(n=8192, k=7, T=200, critics=True, partition="streams"
                       False: "5 policy launches one after the other on one stream + ONE env launch"}[partition] + " per joint step"
                    + (" (actors + critics)" if critics else " (actors)"),
            "kitchens_total": kitchens, "us_per_joint_step": round(sec * 1e6 / T, 1), "agent_env_steps_per_s": round(2 * kitchens * T / sec),
-           "cu_shares": ro.cu_shares}
+           "cu_shares": getattr(ro, "cu_shares", None)}
     ro.close()
     grp.close(close_engines=True)
     return out

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Where does the time go on CU-partitioned streams?  Five layouts (config 3 shape, actors only), shares as GroupPairedRollout
+"""Where does the time go on CU-partitioned streams?  Five layouts (config 3 shape, actors only), shares as tools/exp_group_streams.py
 picks them: each layout's policy launch and env launch timed alone on its masked stream, then all five side by side."""
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup, GroupPairedRollout, OvercookedEngine, PackedNetworks, get_base_layout_params, native
+from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup, OvercookedEngine, PackedNetworks, get_base_layout_params, native
+from exp_group_streams import StreamedGroupPairedRollout
 
 k, n = 7, 8192
 threads = n // (2 * k + 1)
@@ -22,7 +23,7 @@ for name in CLASSIC_LAYOUTS:
     nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors))
     engines.append(OvercookedEngine(params, threads * G, 0))
 grp = EngineGroup(engines)
-ro = GroupPairedRollout(grp, nets, threads, k)
+ro = StreamedGroupPairedRollout(grp, nets, threads, k, mode="cus")
 L = native.lib()
 streams = [torch.cuda.ExternalStream(ro._streams[i]) for i in range(5)]
 cus = ro.cu_shares
@@ -41,18 +42,18 @@ def policy(i, masked=True):
     st = streams[i] if masked else torch.cuda.current_stream()
     with torch.cuda.stream(st):
         sh = ro._shapes[i]
-        native.check(L.oc_policy_forward_cus(ctypes.byref(sh), ctypes.c_void_p(nets[i].image.data_ptr()), nets[i].n_nets,
+        native.check(L.oc_exp_policy_forward_cus(ctypes.byref(sh), ctypes.c_void_p(nets[i].image.data_ptr()), nets[i].n_nets,
                                              ctypes.c_void_p(engines[i].obs.data_ptr()), 2 * engines[i].num_kitchens, ctypes.c_void_p(ro.plans[i].tiles.data_ptr()),
                                              ro.plans[i].n_tiles, None, ctypes.c_void_p(ro.actions[i].data_ptr()), ctypes.c_void_p(ro.logp[i].data_ptr()), None, 1, 0, 0, None, None,
                                              cus[i] if masked else 0, ctypes.c_void_p(st.cuda_stream)))
 
 
 def env(i, masked=True):
-    L.oc_set_cu_budget(engines[i]._handle, cus[i] if masked else 0)
+    L.oc_exp_set_cu_budget(engines[i]._handle, cus[i] if masked else 0)
     st = streams[i] if masked else torch.cuda.current_stream()
     with torch.cuda.stream(st):
         engines[i].step(ro.actions[i])
-    L.oc_set_cu_budget(engines[i]._handle, 0)
+    L.oc_exp_set_cu_budget(engines[i]._handle, 0)
 
 
 out = {"cu_shares": cus, "tiles": [p.n_tiles for p in ro.plans]}
