@@ -10,7 +10,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "liboc_hip.so")
+# OC_SANITIZE=1: the ASan + UBSan build of the library's HOST code (planners, JIT source generation, cache I/O, argument checks;
+# the device code is not instrumented -- GPU sanitizers need xnack+ code objects, which the pool refuses).  CPU-only use:
+#   OC_SANITIZE=1 LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 \
+#       python -m pytest tests -m "not gpu" -k "abi or plan or planner or jit"          (tools/run_sanitized.sh)
+SANITIZE = os.environ.get("OC_SANITIZE", "0") not in ("", "0")
+LIB_PATH = os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
 HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h")]
@@ -108,7 +113,8 @@ def build(force=False, verbose=False):
     # engine itself has no floating point
     # -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs (policy_ops.hip reads them with VALU ops; the
     # accumulator-file form cost 64 v_accvgpr_read per conv position and kept the kernel at one wavefront per SIMD)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+    opt = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-shared-libsan"] if SANITIZE else ["-O3"]
+    cmd = ["hipcc", "--offload-arch=gfx950"] + opt + ["-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-fPIC", "-shared", "-I", INCLUDE, "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
     if verbose:
         print(" ".join(cmd))
