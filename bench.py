@@ -471,7 +471,7 @@ def main():
           torch.cuda.synchronize()
           step_us = (time.perf_counter() - t1) / psteps * 1e6
           rows = 2 * eng2.num_kitchens
-          cycles = rows / 32 * 32 * (P * (6 * 4 + 24) + 48 + 24)     # MFMA issue cycles (i8 conv digits + bf16 piece products), DESIGN 9a
+          cycles = rows / 32 * 32 * (P * (6 * nets.digits + 24) + 48 + 24)     # MFMA issue cycles (i8 conv digits + bf16 piece products), DESIGN 9a
           cus = torch.cuda.get_device_properties(local).multi_processor_count
           bound_us = cycles / (4 * cus) / 2400.0
           policy = {"what": f"{k + 1} conventions in {2 * k + 1} pairing segments of {threads} kitchens: every actor, both sides, in one "
@@ -481,12 +481,12 @@ def main():
                     "checked": check_policy_in_loop(ro, eng2, params),
                     "checked_note": "after the timed steps: 24 more steps recorded into a trajectory, 4 x 64 kitchens spread over the pairing "
                                     "segments replayed through the CPU oracle with the recorded actions (obs, reward, done bit-identical)",
-                    "policy_kernel": {"kernel": "oc_policy_kernel<4 digits>", "us_per_launch": pol_us, "network_evaluations": rows,
+                    "policy_kernel": {"kernel": f"oc_policy_kernel<{nets.digits} digits>", "us_per_launch": pol_us, "network_evaluations": rows,
                                       "useful_TFLOPs": rows * 2 * (P * 180 * 32 + P * 32 * 64 + 64 * 64 + 64 * 6) / pol_us * 1e-6,
                                       "bound": "mfma", "issue_bound_us_at_2.4GHz": bound_us, "frac": bound_us / pol_us,
-                                      "note": "matrix cycles per 32 rows: 11 520 (i8 conv digits + bf16 piece products for the dense layers; 23 040 "
-                                              "with f32 MFMAs in round 1, when this launch took 77.7 us); the VALU work between the layers "
-                                              "(~1780 instructions per block) does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
+                                      "note": "matrix cycles per 32 rows: 10 368 (three base-256 i8 conv digits + bf16 piece products for the dense "
+                                              "layers; 11 520 with four base-128 digits in round 2, 23 040 with f32 MFMAs in round 1); the VALU work "
+                                              "between the layers does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
           eng2.close()
       except Exception as exc:                             # noqa: BLE001
         policy = {"error": f"{type(exc).__name__}: {exc}"}

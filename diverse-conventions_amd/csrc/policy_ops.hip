@@ -9,9 +9,9 @@
 // Network = reference CNNBase + Linear head (train/MAPPO/utils/cnn.py:12-60; hidden_size 64).  Per 32 rows:
 //   conv 3x3  : 6 x digits  v_mfma_i32_32x32x32_i8 per conv position.  Observations are small integers, so they
 //               are fed as int8 without conversion; the f32 weights are split once, at pack time, into `digits`
-//               base-128 fixed-point digits per output channel (policy_pack.h).  Integer accumulation is exact;
-//               with 4 digits the weight quantisation (2^-28 of the channel's largest weight) is below the f32
-//               rounding of the reference's own accumulation.
+//               base-256 fixed-point digits per output channel (policy_pack.h).  Integer accumulation is exact;
+//               with 3 digits the weight quantisation (2^-23 of the channel's largest weight: the f32 spacing of
+//               that weight) is of the class of the f32 rounding of the reference's own accumulation.
 //   fc1/fc2/head : v_mfma_f32_32x32x16_bf16 on exact three-way bf16 splits of both operands (six piece products per
 //               f32 product, f32 accumulate; policy_pack.h): what is dropped is below 2^-23 of each product, and a
 //               32x32x16 tile costs 6 x 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64.  The weights are split at
@@ -22,7 +22,7 @@
 //
 // Bound: MFMA issue + the VALU work between the layers (tools/probes/coexec.hip: they do not overlap on one SIMD).
 // MFMA cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 24*32) + 48*32 + 24*32; cramped_room
-// (P = 6, 4 digits) 11 520 cycles (23 040 with f32 MFMAs for the dense layers, as in round 1).  Bytes: rows are read
+// (P = 6, 3 digits) 10 368 cycles (11 520 with four base-128 digits in round 2, 23 040 with f32 MFMAs for the dense layers in round 1).  Bytes: rows are read
 // once (W*H*20 B each).
 //
 // Shape of the kernel (DESIGN.md 9a has the measurements behind each choice):
@@ -198,8 +198,33 @@ __device__ __forceinline__ float relu(float x) {
 }
 
 // Two f32 activations -> one packed dword per bf16 piece, x = hi + mid + lo exactly: the top 16 bits of an f32 are a
-// bf16 (truncation), what is left after subtracting it has at most 16 significant bits, and so on.
+// bf16 (truncation), what is left after subtracting it has at most 16 significant bits, and so on.  The byte permute that
+// packs the two truncated values comes first; taking them off again is ONE instruction per value, v_dot2c_f32_bf16
+// (acc += a.lo * b.lo + a.hi * b.hi) against the constants {-1, 0} / {0, -1}: the products are exact and x - trunc(x) is
+// representable, so no rounding can show (tools/probes/split_bf16.hip compares it bit for bit with the AND / subtract form
+// on 2^25 pairs).  7 VALU per pair where two AND + one packed subtract per level + three permutes cost 9.
+#ifndef OC_SPLIT_DOT2C
+#define OC_SPLIT_DOT2C 1
+#endif
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float x0, float x1, int &hi, int &mid, int &lo) {
+#if OC_SPLIT_DOT2C
+    // {-1, 0} and {0, -1}, kept in SGPRs behind an empty asm: as a plain constant hipcc 7.2 folds 0x0000bf80 into the inline
+    // operand "-1.0", which the instruction reads as the f32 pattern 0xbf800000 = {0, -1} -- the other constant
+    // (tools/probes/split_bf16.hip caught it: every first element's remainder came out as x0 - trunc(x1))
+    uint32_t k_lo = 0x0000bf80u, k_hi = 0xbf800000u;
+    asm volatile("" : "+s"(k_lo), "+s"(k_hi));
+    const v2bf m_lo = __builtin_bit_cast(v2bf, k_lo), m_hi = __builtin_bit_cast(v2bf, k_hi);
+    const uint32_t h = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, h), m_lo, x0, false);
+    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, h), m_hi, x1, false);
+    const uint32_t m = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    const float q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, m), m_lo, r0, false);
+    const float q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, m), m_hi, r1, false);
+    hi = static_cast<int>(h);
+    mid = static_cast<int>(m);
+    lo = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u));
+#else
     const v2f xv = {x0, x1};
     const v2f hv = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
     const v2f rv = xv - hv;
@@ -208,6 +233,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, int &hi, int &mid
     hi = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u));
     mid = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(rv.y), __float_as_uint(rv.x), 0x07060302u));
     lo = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(qv.y), __float_as_uint(qv.x), 0x07060302u));
+#endif
 }
 
 // fragment f (0..11) of position p of the fc1 section: voffset = lane * 16 (+ immediate), soffset scalar
@@ -342,19 +368,28 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     bool trace_done = false, trace2_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
-    // conv result -> fc1 operand: relu(f32(sum of digit accumulators)), one accumulator register.  The channel's bias is
-    // already in the sum (the lowest digit's accumulator starts from it) and its scale is folded into the fc1 weights.
-    // Digit pairs are pre-combined in integer arithmetic (acc_d * 128 + acc_{d+1}: exact, |.| < 2^31), so four digits cost
-    // 2 shift-adds + 2 conversions + 1 fma instead of 4 conversions + 3 fma: a wave's VALU work is not hidden under its MFMAs.
-    auto combine = [&](const v16i (&acc)[NDIG], int r) -> float {
-        float t;
-        if (NDIG == 1) t = static_cast<float>(acc[0][r]);
-        else {
-            t = static_cast<float>(acc[0][r] * 128 + acc[1][r]);
-            if (NDIG == 3) t = __builtin_fmaf(t, 128.0f, static_cast<float>(acc[2][r]));
-            if (NDIG == 4) t = __builtin_fmaf(t, 16384.0f, static_cast<float>(acc[2][r] * 128 + acc[3][r]));
+    // conv result -> fc1 operand: relu(f32(sum of digit accumulators)), two accumulator registers at a time.  The channel's bias
+    // is already in the sum (the lowest digit's accumulator starts from it) and its scale is folded into the fc1 weights.
+    // The top digit pair is combined in integer arithmetic (acc_0 * B + acc_1: exact, |.| < 2^31), so three digits cost
+    // 1 shift-add + 2 conversions + half a packed fma per register: a wave's VALU work is not hidden under its MFMAs.
+    auto combine_pair = [&](const v16i (&acc)[NDIG], int r, float &x0, float &x1) {
+        constexpr int kB = OC_POLICY_DIGIT_BASE;
+        v2f t;
+        if (NDIG == 1) {
+            t = v2f{static_cast<float>(acc[0][r]), static_cast<float>(acc[0][r + 1])};
+        } else {
+            t = v2f{static_cast<float>(acc[0][r] * kB + acc[1][r]), static_cast<float>(acc[0][r + 1] * kB + acc[1][r + 1])};
+            if (NDIG == 3) {
+                const v2f u = {static_cast<float>(acc[2][r]), static_cast<float>(acc[2][r + 1])};
+                t = __builtin_elementwise_fma(t, v2f{static_cast<float>(kB), static_cast<float>(kB)}, u);
+            }
+            if (NDIG == 4) {
+                const v2f u = {static_cast<float>(acc[2][r] * kB + acc[3][r]), static_cast<float>(acc[2][r + 1] * kB + acc[3][r + 1])};
+                t = __builtin_elementwise_fma(t, v2f{static_cast<float>(kB * kB), static_cast<float>(kB * kB)}, u);
+            }
         }
-        return fmaxf(t, 0.f);
+        x0 = relu(t.x);
+        x1 = relu(t.y);
     };
     auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
 #pragma unroll
@@ -518,7 +553,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
         auto make_operand = [&](v4i (&dst)[3][2], int j) {            // pair j = accumulator registers 2j, 2j + 1
             int hi, mid, lo;
-            split_pair(combine(acc, 2 * j), combine(acc, 2 * j + 1), hi, mid, lo);
+            float x0, x1;
+            combine_pair(acc, 2 * j, x0, x1);
+            split_pair(x0, x1, hi, mid, lo);
             dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = mid; dst[2][j >> 2][j & 3] = lo;
         };
         v4i xb[3][2];
@@ -562,7 +599,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 h1[1] = mfma_bf16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
                 if (!kLast && t < 4) {
                     int hi, mid, lo;
-                    split_pair(combine(acc, 8 + 2 * t), combine(acc, 9 + 2 * t), hi, mid, lo);
+                    float x0, x1;
+                    combine_pair(acc, 8 + 2 * t, x0, x1);
+                    split_pair(x0, x1, hi, mid, lo);
                     nb1[0][t] = hi; nb1[1][t] = mid; nb1[2][t] = lo;
                 }
             }

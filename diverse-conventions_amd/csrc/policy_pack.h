@@ -42,6 +42,10 @@
 #define OC_POLICY_SLAB 64                   /* k per kernel column kx: 3 tiles x 20 channels = 60, padded */
 #define OC_POLICY_HEADER_BYTES 64
 #define OC_POLICY_FC1_POS_BYTES (3 * 2 * 2 * 64 * 16)   /* fc1 fragments of one conv position */
+/* conv weights are fixed-point numbers of `digits` signed int8 digits in this base: digit 0 (the top one) in [-127, 127], the others
+ * balanced in [-BASE/2, BASE/2 - 1].  256 uses every bit of an int8 MFMA operand: 3 digits = 24 bits, the mantissa of the f32 weights
+ * themselves (round 2 used base 128: 4 digits = 28 bits at 24 integer MFMAs per conv position instead of 18). */
+#define OC_POLICY_DIGIT_BASE 256
 
 // Byte offsets of the sections of one packed network (all multiples of 16).
 struct oc_policy_layout {
@@ -94,7 +98,7 @@ OC_HD inline float oc_policy_conv_absmax(const float *conv_w, int o) {
 
 OC_HD inline long long oc_policy_qmax(int digits) {
     long long q = 126;
-    for (int i = 1; i < digits; ++i) q *= 128;
+    for (int i = 1; i < digits; ++i) q *= OC_POLICY_DIGIT_BASE;
     return q;
 }
 
@@ -122,9 +126,10 @@ OC_HD inline int32_t oc_policy_conv_bias_units(const oc_policy_weights &w, int o
     return (int32_t)(x < 0 ? x - 0.5 : x + 0.5);
 }
 
-// Fixed-point conv weight: w ~ scale * sum_d digit_d * 128^(digits-1-d), digit 0 the top digit in [-127, 127], the others
-// balanced in [-64, 63].  With 4 digits and scale = absmax / qmax the quantisation step is absmax * 2^-28: below the f32
-// rounding of the reference's own accumulation.
+// Fixed-point conv weight: w ~ scale * sum_d digit_d * BASE^(digits-1-d), digit 0 the top digit in [-127, 127], the others
+// balanced in [-BASE/2, BASE/2 - 1].  With 3 digits and scale = absmax / qmax the quantisation step is absmax * 2^-23 -- the
+// spacing of the f32 weights next to the channel's largest, i.e. the class of the reference's own f32 rounding (its conv
+// accumulates 180 products, each rounded at 2^-24 of the running sum); 4 digits: absmax * 2^-31.
 OC_HD inline int oc_policy_conv_digit(float w, float scale, int digits, int d) {
     if (!(scale > 0.f) || !(w == w)) return 0;
     const long long qmax = oc_policy_qmax(digits);
@@ -134,12 +139,13 @@ OC_HD inline int oc_policy_conv_digit(float w, float scale, int digits, int d) {
     long long q = (long long)(x < 0 ? x - 0.5 : x + 0.5);
     if (q > qmax) q = qmax;
     if (q < -qmax) q = -qmax;
+    const long long B = OC_POLICY_DIGIT_BASE, half = OC_POLICY_DIGIT_BASE / 2;
     for (int i = digits - 1; i > d; --i) {                          // strip the lower digits
-        long long r = ((q + 64) % 128 + 128) % 128 - 64;            // balanced residue in [-64, 63]
-        q = (q - r) / 128;
+        long long r = ((q + half) % B + B) % B - half;              // balanced residue in [-B/2, B/2 - 1]
+        q = (q - r) / B;
     }
     if (d == 0) return (int)q;
-    return (int)(((q + 64) % 128 + 128) % 128 - 64);
+    return (int)(((q + half) % B + B) % B - half);
 }
 
 // ---- element functions: value of packed element `idx` of each section -------------------------------------

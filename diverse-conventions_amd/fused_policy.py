@@ -41,14 +41,17 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def packed_bytes(width, height, digits=4):
+DEFAULT_DIGITS = 3          # base-256 conv weight digits: 24 bits, the mantissa of the f32 weights (csrc/policy_pack.h)
+
+
+def packed_bytes(width, height, digits=DEFAULT_DIGITS):
     n = native.lib().oc_policy_packed_bytes(ctypes.byref(_shape(width, height, 1, digits)))
     if n < 0:
         native.check(int(n))
     return int(n)
 
 
-def pack_host(state_dict, obs_shape, head=ACTOR_HEAD, digits=4) -> np.ndarray:
+def pack_host(state_dict, obs_shape, head=ACTOR_HEAD, digits=DEFAULT_DIGITS) -> np.ndarray:
     """Weight image of one reference-format network as a uint8 array (host packer; tests, inspection)."""
     W, H = int(obs_shape[0]), int(obs_shape[1])
     arrs = [np.ascontiguousarray(np.asarray(state_dict[k], dtype=np.float32)) for k in _KEYS]
@@ -67,7 +70,7 @@ class PackedNetworks:
     `pack(i, state_dict, head)` converts reference-format tensors (host or device) on the device; call it again
     after every optimiser step for the networks that changed."""
 
-    def __init__(self, obs_shape, n_nets, device, digits=4):
+    def __init__(self, obs_shape, n_nets, device, digits=DEFAULT_DIGITS):
         self.W, self.H = int(obs_shape[0]), int(obs_shape[1])
         if len(obs_shape) > 2 and int(obs_shape[2]) != 20:
             raise ValueError("the fused kernel reads the engine's 20-channel observations")
@@ -102,7 +105,7 @@ class PackedNetworks:
         return index
 
     @classmethod
-    def from_state_dicts(cls, obs_shape, device, actors: Sequence[dict] = (), critics: Sequence[dict] = (), digits=4):
+    def from_state_dicts(cls, obs_shape, device, actors: Sequence[dict] = (), critics: Sequence[dict] = (), digits=DEFAULT_DIGITS):
         """Actors get indices 0..len(actors)-1, critics follow."""
         nets = cls(obs_shape, len(actors) + len(critics), device, digits)
         for i, sd in enumerate(actors):
