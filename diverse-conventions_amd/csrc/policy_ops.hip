@@ -81,6 +81,10 @@ struct PolicySlot {
     float *action_logp;                 // [n_rows]
     float *logp;                        // [n_rows][n_out] or NULL
     const int32_t *row_select;          // [n_rows] or NULL: tiles with a select code only write rows whose entry matches
+    const int32_t *row_index;           // gather tiles: [lists][gather_len] row ids, class 0 first (oc_partition_rows), or NULL
+    const int32_t *row_count;           // gather tiles: [lists][2] entries of either class
+    int gather_len;                     // ids per list
+    int gather_magic;                   // ceil(2^24 / 16-byte pieces per padded LDS row): piece index -> row of the block
     uint32_t seed;
     int pad_;
 };
@@ -167,6 +171,51 @@ __device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, l
     }
 }
 
+// The same for GATHERED rows (OC_POLICY_TILE_GATHER: the rows a tile evaluates are listed in an index array -- mixed play gives
+// every row to one of two policies, and each policy's tile reads only its own rows).  LDS-DMA writes lane l's 16 bytes at
+// base + 16 l whatever the lane's global address is, so the staging area is filled flat, 1 KB per instruction, exactly as above,
+// and only the global side is indirect: piece f of the block belongs to row f / ppr of the block (ppr = 16-byte pieces per
+// row, rows padded to whole pieces in LDS) and comes from that row's address in the observation tensor.  A row of a grid with
+// W*H % 4 != 0 is not a whole number of pieces: its last piece reads up to 12 bytes of the following row (global_load_lds
+// takes dword-aligned addresses on both sides, tools/probes/lds_dma_align.hip); for the tensor's very last row it reads the row's
+// last 16 bytes instead and the consumer repairs those few bytes at its landing wait.  Eight instructions share one LDS base
+// (M0) through the immediate offset, which is added to BOTH addresses -- hence subtracted from the global one first.
+// Returns the row id held by lane & 31 (rows past the tile's end repeat its last row: read, never stored).
+__device__ __forceinline__ int stage_rows_gather(const PolicySlot &a, uint8_t *ldsw, const int32_t *gidx, int first, int nrows, int lane) {
+    const int ppr = (a.RB + 15) >> 4, total = 32 * ppr, n_kb = (total + 63) >> 6;
+    const int my = gidx[min(first + (lane & 31), nrows - 1)];
+    const bool ragged = (a.RB & 15) != 0;
+    const int last_row = static_cast<int>(a.n_rows - 1);
+    auto src_of = [&](int it) -> const int8_t * {
+        const int f = min(it * 64 + lane, total - 1);                 // (lanes past the block re-read its last piece into the slack)
+        const int row = static_cast<int>((static_cast<uint32_t>(f) * static_cast<uint32_t>(a.gather_magic)) >> 24);
+        const int piece = f - row * ppr;
+        const int id = __builtin_amdgcn_ds_bpermute(row << 2, my);
+        int off = piece * 16;
+        if (ragged) off = (id == last_row && piece == ppr - 1) ? a.RB - 16 : off;
+        return a.obs + static_cast<long long>(id) * a.RB + off;
+    };
+#define OC_DMAG(J) { const int8_t *sj = src_of(it + (J)) - ((J) - 4) * 1024; __builtin_amdgcn_global_load_lds((gptr_t)sj, (lptr_t)d4, 16, ((J) - 4) * 1024, 0); }
+    int it = 0;
+    for (; it + 8 <= n_kb; it += 8) {
+        uint8_t *d4 = ldsw + (it + 4) * 1024;
+        OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) OC_DMAG(3) OC_DMAG(4) OC_DMAG(5) OC_DMAG(6) OC_DMAG(7)
+    }
+    uint8_t *d4 = ldsw + (it + 4) * 1024;
+    switch (n_kb - it) {
+    case 7: OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) OC_DMAG(3) OC_DMAG(4) OC_DMAG(5) OC_DMAG(6) break;
+    case 6: OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) OC_DMAG(3) OC_DMAG(4) OC_DMAG(5) break;
+    case 5: OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) OC_DMAG(3) OC_DMAG(4) break;
+    case 4: OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) OC_DMAG(3) break;
+    case 3: OC_DMAG(0) OC_DMAG(1) OC_DMAG(2) break;
+    case 2: OC_DMAG(0) OC_DMAG(1) break;
+    case 1: OC_DMAG(0) break;
+    default: break;
+    }
+#undef OC_DMAG
+    return my;
+}
+
 // B operands of the conv at one position: for each kernel column kx the 60 contiguous bytes of tiles
 // (x'+kx, y'..y'+2) plus 4 bytes that meet zero weights, as 2 x 16 bytes per lane half.
 __device__ __forceinline__ void read_bfrags(const uint8_t *rowp, int pos_off, int colstep, v4i (&bfr)[6]) {
@@ -248,10 +297,16 @@ __device__ __forceinline__ v4i w1_from_l2(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 // stretch of blocks [wg0, wg1) that may run through several tiles (weights are reloaded only when the network changes along
 // it); a planned table -- about one balanced tile per CU, oc_policy_plan_tiles -- maps tile i to workgroup i instead.
 // Everything is wave-uniform.  Returns false when the workgroup has no block.
-__device__ __forceinline__ int policy_tile_blocks(const long long n_rows, const int4 t) {
+// rows a gather tile {list, class, net, flags} evaluates: what oc_partition_rows counted for that class of that list
+__device__ __forceinline__ int policy_gather_rows(const PolicySlot &S, const int4 t) {
+    if (!S.row_index || !S.row_count || t.x < 0) return 0;
+    return min(max(S.row_count[2 * t.x + (t.y & 1)], 0), S.gather_len);
+}
+__device__ __forceinline__ int policy_tile_blocks(const PolicySlot &S, const int4 t) {
+    if (t.w & OC_POLICY_TILE_GATHER) return (policy_gather_rows(S, t) + kRowsPerBlock - 1) / kRowsPerBlock;
     long long nr = t.y;
-    if (t.x < 0 || t.x >= n_rows || nr <= 0) return 0;              // a bad tile contributes nothing
-    if (t.x + nr > n_rows) nr = n_rows - t.x;
+    if (t.x < 0 || t.x >= S.n_rows || nr <= 0) return 0;            // a bad tile contributes nothing
+    if (t.x + nr > S.n_rows) nr = S.n_rows - t.x;
     return static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
 }
 
@@ -262,7 +317,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         const int i = base_tile + lane;
         int4 t = make_int4(0, 0, 0, 0);
         if (i < a.n_tiles) t = a.tiles[i];
-        nb = i < a.n_tiles ? policy_tile_blocks(a.slot[0].n_rows, t) : 0;      // (launches over several slots are always tile-per-workgroup)
+        nb = i < a.n_tiles ? policy_tile_blocks(a.slot[0], t) : 0;             // (launches over several slots are always tile-per-workgroup)
         incl = nb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -282,7 +337,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         wg1 = 0;
         for (int j = 0; j < a.tile_per_wg; ++j) {                    // (wave-uniform)
             const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
-            wg1 += policy_tile_blocks(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0].n_rows, t);
+            wg1 += policy_tile_blocks(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
         }
     } else {
         wg1 = total * (blockIdx.x + 1) / gridDim.x;
@@ -444,19 +499,31 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         wstart = static_cast<int>(T.L.off_b1);
     }
     const PolicySlot &S = a.slot[MULTI ? cur_slot : 0];
-    const int tnb = policy_tile_blocks(S.n_rows, tile);
+    const int tnb = policy_tile_blocks(S, tile);
     if (tnb == 0) { ++ti; continue; }
     const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
     const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);   // this stretch of the tile
-    const long long row0 = tile.x;
-    const int nrows = static_cast<int>(row0 + tile.y > S.n_rows ? S.n_rows - row0 : tile.y);
+    // a gather tile {list, class, net, flags} evaluates the rows listed for that class of that list (oc_partition_rows: class 0's ids
+    // first, class 1's behind them); its rows are staged padded to whole 16-byte pieces
+    const bool gather = (tile.w & OC_POLICY_TILE_GATHER) != 0;
+    const int32_t *gidx = gather ? S.row_index + static_cast<long long>(tile.x) * S.gather_len + ((tile.y & 1) ? policy_gather_rows(S, make_int4(tile.x, 0, 0, 0)) : 0)
+                                 : nullptr;
+    const long long row0 = gather ? 0 : tile.x;
+    const int nrows = gather ? policy_gather_rows(S, tile) : static_cast<int>(row0 + tile.y > S.n_rows ? S.n_rows - row0 : tile.y);
     const int net = min(max(tile.z, 0), S.n_nets - 1);
-    const int flags = tile.w;
+    const int flags = gather ? (tile.w & ~0xff00) : tile.w;           // (a gather tile needs no select code: it only has its own rows)
+    const int RS = gather ? (RB + 15) & ~15 : RB;                     // LDS row stride
+    rowp = ldsw + col * RS + 16 * h;
     cur = run_end;
     if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
+    int myrow_next = 0;                                               // gather: row id of lane & 31 in the block being staged
+    auto stage = [&](int b) {
+        if (gather) myrow_next = stage_rows_gather(S, ldsw, gidx, b * kRowsPerBlock, nrows, lane);
+        else stage_rows(S, ldsw, row0 + static_cast<long long>(b) * kRowsPerBlock, lane);
+    };
 
     // this wavefront's first block of the stretch: in flight while (if) the weights are fetched
-    if (first + wave < last) stage_rows(S, ldsw, row0 + static_cast<long long>(first + wave) * kRowsPerBlock, lane);
+    if (first + wave < last) stage(first + wave);
     if (net != loaded_net || (MULTI && cur_slot != loaded_slot)) {
         __syncthreads();                                              // everybody is done with the previous network
         const uint8_t *blob = S.packed + static_cast<size_t>(net) * S.L.total;
@@ -509,6 +576,21 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (traced) stamp(a, wave, lane, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
         wave_lds_sync();
+        const int myrow = myrow_next;
+        if (gather && (RB & 15)) {
+            // the one row whose last piece could not over-read (the tensor's last row, see stage_rows_gather): its final bytes again,
+            // dword by dword -- at most one row per launch, so this branch is all but never taken
+            const bool fix = h == 0 && col + blk * kRowsPerBlock < nrows && myrow == static_cast<int>(S.n_rows - 1);
+            if (__ballot(fix)) {
+                if (fix) {
+                    const int tail0 = (RB >> 4) << 4;
+                    const uint32_t *sp = reinterpret_cast<const uint32_t *>(S.obs + static_cast<long long>(myrow) * RB + tail0);
+                    uint32_t *dp = reinterpret_cast<uint32_t *>(ldsw + col * RS + tail0);
+                    for (int q = 0; q < (RB & 15) >> 2; ++q) dp[q] = sp[q];
+                }
+                wave_lds_sync();
+            }
+        }
         if (traced) stamp(a, wave, lane, 3);
         if (traced2) stamp(a, wave, lane, 17);
         // A tile with a select code skips the blocks none of whose rows it would write (mixed play: the stretch of
@@ -517,7 +599,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             const int want = ((flags >> 8) & 0xff) - 1;
             const bool mine = col + blk * kRowsPerBlock < nrows && S.row_select[brow + col] == want;
             if (__ballot(mine) == 0) {
-                if (blk + nwaves < last) stage_rows(S, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+                if (blk + nwaves < last) stage(blk + nwaves);
                 continue;
             }
         }
@@ -640,8 +722,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         // (all at once: spreading the LDS-DMA instructions between the MFMA groups of fc2 / head was measured -- each still holds
         // the wavefront for its ~0.1 us, the time just moves there: 99.4 vs 95.2 us per cramped_room launch)
         wave_lds_sync();
-        if (blk + nwaves < last)
-            stage_rows(S, ldsw, row0 + static_cast<long long>(blk + nwaves) * kRowsPerBlock, lane);
+        if (blk + nwaves < last) stage(blk + nwaves);
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 27);
 
@@ -718,7 +799,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
 
         // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
         //      work on their own actions and meet through three lane exchanges ----
-        const long long row = brow + col;
+        const long long row = gather ? myrow : brow + col;
         bool valid = (blk * kRowsPerBlock + col) < nrows;
         const int sel = (flags >> 8) & 0xff;                          // OC_POLICY_TILE_SELECT(v): only rows with row_select == v
         if (sel && S.row_select && valid) valid = S.row_select[row] == sel - 1;
@@ -1054,8 +1135,20 @@ int fill_slot(PolicySlot &t, const oc_policy_shape *shape, const void *d_packed,
     t.n_rows = n_rows;
     if (n_rows * t.RB < 16) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: input smaller than 16 bytes");
     t.raw = d_raw; t.actions = d_actions; t.action_logp = d_action_logp; t.logp = d_logp; t.row_select = d_row_select;
+    t.row_index = nullptr; t.row_count = nullptr; t.gather_len = 0; t.gather_magic = 0;
     t.seed = seed;
     t.pad_ = 0;
+    return OC_OK;
+}
+
+// Index lists for gather tiles (oc_partition_rows): n_lists lists of gather_len row ids with their two class counts.
+int fill_gather(PolicySlot &t, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len) {
+    if (!d_row_index || !d_row_count || gather_len < 1 || gather_len > t.n_rows)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_gather: NULL index / count arrays, or a list length outside 1 .. n_rows");
+    t.row_index = d_row_index; t.row_count = d_row_count;
+    t.gather_len = static_cast<int>(gather_len);
+    const int ppr = (t.RB + 15) >> 4;                                  // 16-byte pieces per padded LDS row
+    t.gather_magic = ((1 << 24) + ppr - 1) / ppr;                      // f / ppr == (f * magic) >> 24 for every piece index of a block
     return OC_OK;
 }
 
@@ -1066,7 +1159,11 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     const PolicySlot &s0 = a.slot[0];
     a.trace = g_trace;
     a.lds_wave_bytes = 0;
-    for (int i = 0; i < a.n_slots; ++i) a.lds_wave_bytes = std::max(a.lds_wave_bytes, staging_bytes(a.slot[i].RB));
+    for (int i = 0; i < a.n_slots; ++i) {
+        a.lds_wave_bytes = std::max(a.lds_wave_bytes, staging_bytes(a.slot[i].RB));
+        if (a.slot[i].row_index)                                       // gathered rows are staged padded to whole 16-byte pieces, in whole 1 KB instructions
+            a.lds_wave_bytes = std::max(a.lds_wave_bytes, (kRowsPerBlock * ((a.slot[i].RB + 15) & ~15) + 1023) / 1024 * 1024);
+    }
     constexpr long long kLds = 160 * 1024;
     const long long w_tail_all = s0.L.off_bh + 32 - s0.L.off_fc1, w_tail_small = s0.L.off_bh + 32 - s0.L.off_b1;
     const long long w_conv = s0.L.off_fc1 - s0.L.off_conv, obs1 = a.lds_wave_bytes;
@@ -1157,10 +1254,10 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
 
 extern "C" {
 
-int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
-                              const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
-                              float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
-                              const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                               const int32_t *d_tiles, int32_t n_tiles, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len,
+                               float *d_raw, int32_t *d_actions, float *d_action_logp, float *d_logp, int sample_mode, uint32_t seed,
+                               uint32_t counter, const uint32_t *d_counter, const int32_t *d_row_select, int32_t cu_budget, void *stream) {
     if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
     if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_tiles NULL or not 16-byte aligned");
@@ -1168,12 +1265,31 @@ int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed
     PolicyArgs a;
     memset(&a, 0, sizeof(a));
     if (int rc = fill_slot(a.slot[0], shape, d_packed, n_nets, d_obs, n_rows, d_raw, d_actions, d_action_logp, d_logp, d_row_select, seed)) return rc;
+    if (d_row_index || d_row_count)
+        if (int rc = fill_gather(a.slot[0], d_row_index, d_row_count, gather_len)) return rc;
     if (n_tiles == 0) return OC_OK;
     a.n_slots = 1;
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.n_tiles = n_tiles;
     a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
     return launch_policy(a, shape->digits, false, cu_budget, static_cast<hipStream_t>(stream));
+}
+
+int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                              const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                              float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                              const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+    return policy_forward_impl(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, nullptr, nullptr, 0, d_raw, d_actions, d_action_logp, d_logp,
+                               sample_mode, seed, counter, d_counter, d_row_select, cu_budget, stream);
+}
+
+int oc_policy_forward_gather(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                             const int32_t *d_tiles, int32_t n_tiles, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len,
+                             float *d_raw, int32_t *d_actions, float *d_action_logp, float *d_logp, int sample_mode, uint32_t seed,
+                             uint32_t counter, const uint32_t *d_counter, void *stream) {
+    if (!d_row_index || !d_row_count) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward_gather: NULL index / count arrays");
+    return policy_forward_impl(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_row_index, d_row_count, gather_len, d_raw, d_actions,
+                               d_action_logp, d_logp, sample_mode, seed, counter, d_counter, nullptr, 0, stream);
 }
 
 int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, const int32_t *d_tiles, int32_t n_tiles, int32_t tiles_per_workgroup,
@@ -1229,6 +1345,34 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
                                        counter0 + static_cast<uint32_t>(t), nullptr, d_row_select ? d_row_select + t * rows : nullptr, stream))
             return rc;
         if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n, stream)) return rc;
+    }
+    return OC_OK;
+}
+
+int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
+                            int32_t n_tiles, int64_t T, int8_t *d_obs, int32_t *d_actions, float *d_action_logp, float *d_values,
+                            int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0, const int32_t *d_choice,
+                            int32_t *d_index_ws, int32_t *d_count_ws, void *stream) {
+    if (!e || !d_obs || !d_actions || !d_reward || !d_done || !d_choice || !d_index_ws || !d_count_ws || T < 0)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout_mixed: NULL pointer or negative T");
+    int64_t shp[5];
+    if (int rc = oc_obs_shape(e, shp)) return rc;
+    if (shp[0] != 2 || shp[4] != OC_POLICY_C) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_rollout_mixed: the fused policy kernel reads 2-player observations");
+    if (!shape || shp[2] != shape->width || shp[3] != shape->height)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout_mixed: the networks' grid does not match the engine's");
+    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
+    const OcDeviceScope on_device(oc_device_id(e));
+    if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout_mixed: cannot make device %d current", oc_device_id(e));
+    // every step's rows sorted by who plays them, for all steps at once: list 2t + side holds row ids side * N + kitchen
+    if (int rc = oc_partition_rows(d_choice, 2 * T, n, 2, d_index_ws, d_count_ws, stream)) return rc;
+    for (int64_t t = 0; t < T; ++t) {
+        int32_t *act_t = d_actions + t * rows;
+        // (step t reads slot t and the env step writes slot t + 1: the 12 bytes a ragged row's last piece may over-read lie inside the buffer)
+        if (int rc = oc_policy_forward_gather(shape, d_packed, n_nets, d_obs + t * slot, rows, d_tiles, n_tiles, d_index_ws + t * rows, d_count_ws + t * 4, n,
+                                              d_values ? d_values + t * rows : nullptr, act_t, d_action_logp ? d_action_logp + t * rows : nullptr,
+                                              nullptr, sample_mode, seed, counter0 + static_cast<uint32_t>(t), nullptr, stream))
+            return rc;
+        if (int rc = oc_step(e, act_t, OC_ACT_I32, d_obs + (t + 1) * slot, d_reward + t * rows, d_done + t * n, stream)) return rc;
     }
     return OC_OK;
 }

@@ -532,3 +532,75 @@ extern "C" int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t
     hipLaunchKernelGGL(oc_gather_records_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? OC_OK : OC_ERR_HIP;
 }
+
+// ---- stable two-way partition of row ids (mixed play) -------------------------------------------------
+// The reference picks, per environment and step, which of two policies acts and evaluates each policy on the rows it was given
+// (`mix_mask == i` indexing, train/partner_agents.py:171-196, train/XD/xd_player.py:287-305).  oc_partition_rows turns a batch
+// of such 0/1 choice vectors into index lists the policy kernel's gather tiles read (oc_policy_forward_gather): per list, the ids
+// of the entries with select == 0 in ascending order, then the ids of the others, and both counts.  One workgroup per list, two
+// passes over it (count, then place) with a wavefront-ballot scan per 1024-entry chunk.
+namespace {
+
+__global__ __launch_bounds__(1024) void oc_partition_rows_kernel(const int32_t *select, long long len, long long id_period, int32_t *index,
+                                                                 int32_t *count) {
+    __shared__ int wave_zeros[16];
+    __shared__ int total_zeros;
+    const long long list = blockIdx.x;
+    const int32_t *sel = select + list * len;
+    int32_t *out = index + list * len;
+    const int id0 = static_cast<int>((list % id_period) * len);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 1: zeros in the whole list
+    int zeros = 0;
+    for (long long k = threadIdx.x; k < len; k += 1024) zeros += sel[k] == 0 ? 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) zeros += __shfl_down(zeros, d);
+    if (lane == 0) wave_zeros[wave] = zeros;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_zeros[w];
+        total_zeros = t;
+        count[2 * list] = t;
+        count[2 * list + 1] = static_cast<int>(len) - t;
+    }
+    __syncthreads();
+    const int c0 = total_zeros;
+    // pass 2: place.  run0 / run1: entries of either class placed by the chunks before this one
+    int run0 = 0;
+    for (long long base = 0; base < len; base += 1024) {
+        const long long k = base + threadIdx.x;
+        const bool in = k < len;
+        const bool zero = in && sel[k] == 0;
+        const unsigned long long bz = __ballot(zero);
+        const int before = __popcll(bz & ((1ull << lane) - 1ull));           // zeros of this wavefront below this lane
+        __syncthreads();                                                       // wave_zeros of the previous chunk has been read
+        if (lane == 0) wave_zeros[wave] = __popcll(bz);
+        __syncthreads();
+        int zeros_below = 0, zeros_chunk = 0;
+        for (int w = 0; w < 16; ++w) {
+            zeros_below += w < wave ? wave_zeros[w] : 0;
+            zeros_chunk += wave_zeros[w];
+        }
+        if (in) {
+            const int z_before = run0 + zeros_below + before;                  // zeros among entries [0, k)
+            const int pos = zero ? z_before : c0 + (static_cast<int>(k) - z_before);
+            out[pos] = id0 + static_cast<int>(k);
+        }
+        run0 += zeros_chunk;
+    }
+}
+
+}  // namespace
+
+extern "C" int oc_partition_rows(const int32_t *d_select, int64_t n_lists, int64_t len, int64_t id_period, int32_t *d_index, int32_t *d_count,
+                                 void *stream) {
+    if (!d_select || !d_index || !d_count || n_lists < 0 || len < 1 || id_period < 1 || len * id_period > INT32_MAX || n_lists > INT32_MAX)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_partition_rows: NULL pointer, or sizes outside 1 .. 2^31 - 1 (len * id_period included)");
+    if (n_lists == 0) return OC_OK;
+    const OcDeviceScope on_device(oc_device_of_pointer(d_index));
+    hipLaunchKernelGGL(oc_partition_rows_kernel, dim3(static_cast<unsigned>(n_lists)), dim3(1024), 0, static_cast<hipStream_t>(stream), d_select,
+                       static_cast<long long>(len), static_cast<long long>(id_period), d_index, d_count);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_partition_rows: launch failed: %s", hipGetErrorString(err));
+    return OC_OK;
+}

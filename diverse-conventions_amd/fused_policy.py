@@ -19,6 +19,7 @@ from . import native
 ACTOR_HEAD = "act.action_out.linear"        # reference utils/act.py + distributions.py:60-80
 CRITIC_HEAD = "v_out"                       # reference r_actor_critic.py:165
 TILE_ACT = 1                                # OC_POLICY_TILE_ACT
+TILE_GATHER = 16                            # OC_POLICY_TILE_GATHER: the tile is (list, class, net, flags) over an index list
 
 
 def tile_select(v):
@@ -275,6 +276,62 @@ class MultiPolicyPlan:
         dev = self.nets[0].device
         native.check(native.lib().oc_policy_forward_multi(slots, k, _ptr(self.tiles), self.n_tiles, self.tiles_per_workgroup, self.waves_per_workgroup,
                                                           0 if deterministic else 1, int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(dev)))
+
+
+def partition_rows(select, id_period=1, index=None, count=None):
+    """oc_partition_rows: select int32 [..., len] of 0 / non-0 choices (leading axes = lists) -> (index int32 same shape: per list
+    the ids of the entries with choice 0 in ascending order, then the others'; count int32 [..., 2]).  The id of entry k of list
+    l is (l % id_period) * len + k."""
+    if select.dtype != torch.int32 or not select.is_contiguous() or not select.is_cuda:
+        raise ValueError("select must be a contiguous int32 tensor on the GPU")
+    length = select.shape[-1]
+    lists = select.numel() // length
+    index = torch.empty_like(select) if index is None else index
+    count = torch.empty(tuple(select.shape[:-1]) + (2,), dtype=torch.int32, device=select.device) if count is None else count
+    native.check(native.lib().oc_partition_rows(_ptr(select), lists, length, int(id_period), _ptr(index), _ptr(count), _stream(select.device)))
+    return index, count
+
+
+class GatherPlan:
+    """Tile table of a gathered launch (`oc_policy_forward_gather`): `lists` row lists of `length` ids each -- e.g. one per side of
+    the engine's `[P, N]` rows -- every one split in two classes by `partition_rows`; tiles = (list, class, net, flags): network
+    `net` evaluates the rows of `class` in `list`, and nothing else.  The kernel splits the table evenly over the CUs itself (the
+    class counts live on the device), so the table is the same for every step."""
+
+    def __init__(self, nets: PackedNetworks, n_rows: int, length: int, tiles):
+        self.nets, self.n_rows, self.length = nets, int(n_rows), int(length)
+        rows = []
+        for lst, cls, net, flags in tiles:
+            if not 0 <= int(net) < nets.n_nets or int(cls) not in (0, 1) or int(lst) < 0:
+                raise ValueError(f"gather tile ({lst}, {cls}, net {net}) is not (list >= 0, class 0/1, one of {nets.n_nets} networks)")
+            rows.append((int(lst), int(cls), int(net), (int(flags) & 0xFF) | TILE_GATHER))
+        self.tiles = torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(nets.device)
+        self.n_tiles = len(rows)
+        self.counter = 0
+
+    def forward(self, obs, index, count, raw=None, actions=None, action_logp=None, logp=None, deterministic=False, seed=0, counter=None,
+                device_counter=None):
+        nets = self.nets
+        rb = nets.W * nets.H * 20
+        if obs.dtype != torch.int8 or not obs.is_contiguous() or obs.device != nets.device or obs.numel() != self.n_rows * rb:
+            raise ValueError(f"obs must be a contiguous int8 tensor of {self.n_rows} rows x {rb} bytes on {nets.device}")
+        for name, t in (("index", index), ("count", count)):
+            if t.dtype != torch.int32 or not t.is_contiguous() or t.device != nets.device:
+                raise ValueError(f"{name} must be a contiguous int32 tensor on {nets.device}")
+        if index.numel() % self.length or count.numel() != 2 * (index.numel() // self.length):
+            raise ValueError("index holds whole lists of `length` ids, count two entries per list")
+        if int(self.tiles[:, 0].max()) >= index.numel() // self.length:
+            raise ValueError("a tile names a list the index array does not hold")
+        for name, t, dt in (("raw", raw, torch.float32), ("actions", actions, torch.int32),
+                            ("action_logp", action_logp, torch.float32), ("logp", logp, torch.float32)):
+            if t is not None and (t.dtype != dt or not t.is_contiguous() or t.device != nets.device):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor on {nets.device}")
+        if counter is None:
+            counter, self.counter = self.counter, self.counter + 1
+        native.check(native.lib().oc_policy_forward_gather(
+            ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(obs), self.n_rows, _ptr(self.tiles),
+            self.n_tiles, _ptr(index), _ptr(count), self.length, _ptr(raw), _ptr(actions), _ptr(action_logp), _ptr(logp),
+            0 if deterministic else 1, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(nets.device)))
 
 
 def gumbel_uniform(seed, counter, row, action):

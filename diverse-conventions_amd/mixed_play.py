@@ -12,15 +12,17 @@ switch times.  Only the forced stretches are kept, and `diaginsert` / `partinser
 * `MixedPlaySchedule`: kitchen k takes the role of environment `k // ceil(N / (L-1))` (contiguous stretches); `choose(step, uniforms)` is the
   reference's `mix_mask` for a whole `[N]` vector on the device, `gather_index()` the placement map of the two
   inserts as one row index, so the mixed-play buffer is ONE gather out of a time-aligned trajectory.
-* `MixedPlayRollout`: the 2L-step collection itself -- per step one fused policy launch in which the two candidate
-  networks (actors and critics) cover the same rows and each writes only the rows the coin gave it
-  (`OC_POLICY_TILE_SELECT`), and one env launch writing the next trajectory slot.
+* `MixedPlayRollout`: the 2L-step collection itself -- every step's rows are sorted by who plays them (one stable partition of
+  the whole `[2L, P, N]` choice tensor on the device, `oc_partition_rows`), and per step one fused policy launch in which each of
+  the two candidate networks (actor and critic) evaluates exactly the rows the coin gave it, gathered through the index lists
+  (`OC_POLICY_TILE_GATHER`: the reference's `mix_mask == i` indexing, no row is evaluated twice), and one env launch writing the
+  next trajectory slot.
 Pinned by tests/golden/mixed_play_cases.npz, recorded from the reference's own classes.
 """
 import torch
 
 from .engine import OvercookedEngine
-from .fused_policy import TILE_ACT, PolicyPlan, tile_select
+from .fused_policy import TILE_ACT, GatherPlan
 from .rollout_ops import gather_rows
 from .trajectory import TrajectoryBuffer
 
@@ -75,19 +77,19 @@ class MixedPlayRollout:
     rMAPPOWrapper(agent_set[best_i], policy.mp_critic)]` (xd_player.py:235)."""
 
     def __init__(self, engine: OvercookedEngine, nets, length: int, main, partner, ego_id: int = 0, seed: int = 0,
-                 deterministic: bool = False, rows_per_tile=None, generator=None):
+                 deterministic: bool = False, generator=None):
         if int(engine.params["horizon"]) != int(length):
             raise ValueError(f"the engine's horizon ({engine.params['horizon']}) must equal the episode length ({length}): "
                              "both mixed-play episodes end for every kitchen at once")
         self.engine, self.nets, self.L = engine, nets, int(length)
         n = engine.num_kitchens
         self.schedule = MixedPlaySchedule(length, n, engine.device)
-        rows = []
+        tiles = []
         for side in range(2):
             for choice, (actor, critic) in enumerate((main, partner)):
-                rows.append((side * n, n, actor, TILE_ACT | tile_select(choice)))
-                rows.append((side * n, n, critic, tile_select(choice)))
-        self.plan = PolicyPlan(nets, 2 * n, rows, rows_per_tile=rows_per_tile)
+                tiles.append((side, choice, actor, TILE_ACT))
+                tiles.append((side, choice, critic, 0))
+        self.plan = GatherPlan(nets, 2 * n, n, tiles)
         self.ego_id, self.seed, self.deterministic, self.generator = ego_id, seed, deterministic, generator
         # running draw counter: the kernel's Gumbel noise is hash(seed, counter + t, row, action), so every collection
         # must start where the previous one stopped or it would replay the same noise (as FusedPairedRollout.steps_done does)
@@ -97,6 +99,8 @@ class MixedPlayRollout:
         self.logp = torch.zeros((T, 2, n), dtype=torch.float32, device=dev)
         self.values = torch.zeros((T, 2, n), dtype=torch.float32, device=dev)
         self.choice = torch.zeros((T, 2, n), dtype=torch.int32, device=dev)
+        self.index = torch.zeros((T, 2, n), dtype=torch.int32, device=dev)          # rows of every (step, side) sorted by choice
+        self.count = torch.zeros((T, 2, 2), dtype=torch.int32, device=dev)
 
     def collect(self, uniforms=None):
         """Run the two episodes.  uniforms: optional f32 [2L, 2, N] (index 0 = the ego side's draw, 1 = the partner's,
@@ -111,12 +115,12 @@ class MixedPlayRollout:
             uniforms = torch.rand((T, 2, n), device=e.device, generator=self.generator)
         ch = self.schedule.choose_all(uniforms)                                         # [2L, 2, N]: ego draw, partner draw
         self.choice[:, self.ego_id], self.choice[:, 1 - self.ego_id] = ch[:, 0], ch[:, 1]
-        # all 2L steps (policy launch with the per-row choices of the step + env launch) enqueued by one call
-        native.check(native.lib().oc_policy_rollout(
+        # all 2L steps (the partition of every step's rows, then per step a gathered policy launch + the env launch) enqueued by one call
+        native.check(native.lib().oc_policy_rollout_mixed(
             e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
-            self.plan.n_tiles, T, 0, _ptr(self.traj.obs), _ptr(self.traj.actions), _ptr(self.logp), _ptr(self.values),
+            self.plan.n_tiles, T, _ptr(self.traj.obs), _ptr(self.traj.actions), _ptr(self.logp), _ptr(self.values),
             _ptr(self.traj.reward), _ptr(self.traj.done), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF,
-            self.draws_done & 0xFFFFFFFF, _ptr(self.choice), _stream(e.device)))
+            self.draws_done & 0xFFFFFFFF, _ptr(self.choice), _ptr(self.index), _ptr(self.count), _stream(e.device)))
         self.draws_done += T
         self.traj.t = T
         return self

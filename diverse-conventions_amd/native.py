@@ -49,6 +49,7 @@ SYMBOLS_OPS = [
     "oc_gae_returns", "oc_advantage_workspace_bytes", "oc_advantage_normalize", "oc_gather_rows", "oc_gather_columns", "oc_pack_columns", "oc_gather_records",
     "oc_policy_packed_bytes", "oc_policy_pack_host", "oc_policy_pack", "oc_policy_plan_tiles", "oc_policy_forward", "oc_policy_forward_multi",
     "oc_policy_plan_tiles_multi", "oc_group_policy_rollout_multi", "oc_policy_uniform", "oc_policy_rollout", "oc_group_policy_rollout",
+    "oc_partition_rows", "oc_policy_forward_gather", "oc_policy_rollout_mixed",
 ]
 SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
 # include/overcooked_experiments.h (measured and not adopted; tools/ only) and include/overcooked_debug.h (diagnostics)
@@ -182,6 +183,9 @@ def lib():
     L.oc_policy_plan_tiles.argtypes = [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, i64]
     L.oc_policy_plan_tiles.restype = i64
     L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp]
+    L.oc_partition_rows.argtypes = [vp, i64, i64, i64, vp, vp, vp]
+    L.oc_policy_forward_gather.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, i64, vp, vp, vp, vp, i32, u32, u32, vp, vp]
+    L.oc_policy_rollout_mixed.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp, vp]
     L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
     L.oc_exp_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
     L.oc_exp_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]

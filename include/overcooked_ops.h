@@ -85,6 +85,7 @@ typedef struct {
 } oc_policy_shape;
 
 #define OC_POLICY_TILE_ACT 1   /* tile flag: actor epilogue (log-softmax, action draw); otherwise raw head outputs */
+#define OC_POLICY_TILE_GATHER 16   /* tile flag: the tile is {list, class 0/1, net, flags} and evaluates the rows listed for that class (oc_policy_forward_gather) */
 #define OC_POLICY_TILE_SELECT(v) ((((v) + 1) & 0xff) << 8)   /* tile flag: write only rows whose d_row_select entry == v (0..254) */
 
 /* Bytes of one packed network (a function of width, height, digits only; multiple of 256). < 0 on error. */
@@ -123,6 +124,27 @@ int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_
                       float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                       const int32_t *d_row_select, void *stream);
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action);
+
+/* ---- per-row policy mixing without evaluating anything twice ----------------------------------------
+ * The reference's mixed play gives every environment, at every step and on each side, to ONE of two policies and evaluates each
+ * policy on exactly the rows it was given (`mix_mask == i` indexing: train/partner_agents.py:171-196, train/XD/xd_player.py:287-305).
+ * oc_partition_rows: d_select int32 [n_lists][len] of 0 / non-0 choices -> d_index int32 [n_lists][len]: per list the ids of the
+ * entries with choice 0 in ascending order, then the ids of the others; d_count int32 [n_lists][2]: how many of each.  The id of
+ * entry k of list l is (l % id_period) * len + k: with one list per (step, side) and id_period = 2, ids are rows player * N + kitchen
+ * of that step's observation.
+ * oc_policy_forward_gather: oc_policy_forward whose tiles may carry OC_POLICY_TILE_GATHER: such a tile is {list, class, net, flags}
+ * and evaluates rows d_row_index[list * gather_len + (class ? d_row_count[2 list] : 0) + i], i < d_row_count[2 list + class] -- the
+ * kernel stages those rows through indirect LDS-DMA addresses and writes its outputs at the rows' own indices, so two policies
+ * share one output buffer and nobody evaluates a row it does not own.  The table is split evenly over the CUs by the kernel
+ * (the counts live on the device).  Same numerics, same draws per (seed, counter, row) as oc_policy_forward.
+ * When W*H*20 is not a multiple of 16, gathered rows are read in 16-byte pieces that may run up to 12 bytes into the FOLLOWING
+ * row; the tensor's last row is handled, nothing is read past n_rows rows. */
+int oc_partition_rows(const int32_t *d_select, int64_t n_lists, int64_t len, int64_t id_period, int32_t *d_index, int32_t *d_count,
+                      void *stream);
+int oc_policy_forward_gather(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                             const int32_t *d_tiles, int32_t n_tiles, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len,
+                             float *d_raw, int32_t *d_actions, float *d_action_logp, float *d_logp, int sample_mode, uint32_t seed,
+                             uint32_t counter, const uint32_t *d_counter, void *stream);
 /* One launch over SEVERAL observation tensors of different grids (the layouts of an engine group): every slot is what
  * oc_policy_forward takes for one grid; tiles name their slot with OC_POLICY_TILE_SLOT(i) in the flags.
  * oc_policy_plan_tiles_multi lays the 32-row blocks of all segments out as one sequence and gives every workgroup an equal share
@@ -192,6 +214,16 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
                       int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
                       float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
                       const int32_t *d_row_select, void *stream);
+/* The mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) as ONE call: T steps, always time-major
+ * (buffers as oc_policy_rollout with in_place = 0), d_choice int32 [T][2N] = which of the two candidate policies plays row
+ * player * N + kitchen at step t.  The call partitions every step's rows by choice (oc_partition_rows into the caller's workspaces
+ * d_index_ws int32 [T][2N], d_count_ws int32 [T][2][2]) and runs, per step, one oc_policy_forward_gather + one oc_step.
+ * d_tiles: gather tiles {side, choice, net, flags | OC_POLICY_TILE_GATHER}: typically 8 (2 sides x 2 choices x actor / critic). */
+int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
+                            int32_t n_tiles, int64_t T, int8_t *d_obs, int32_t *d_actions, float *d_action_logp, float *d_values,
+                            int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0, const int32_t *d_choice,
+                            int32_t *d_index_ws, int32_t *d_count_ws, void *stream);
+
 
 
 #ifdef __cplusplus

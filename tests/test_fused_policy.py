@@ -503,3 +503,73 @@ def test_the_binding_shown_in_integration_md_runs():
     a = actions.cpu().numpy().astype(np.int64)
     ref = np.concatenate([z["a0.logits"][:120], z["a1.logits"][120:]])
     assert np.abs(logp.cpu().numpy() - np.take_along_axis(ref, a[:, None], 1)[:, 0]).max() < TOL_LOGP
+
+
+# ------------------------------------------------------------------------------------------- gathered rows (mixed play)
+@pytest.mark.gpu
+def test_partition_rows_is_a_stable_two_way_partition():
+    from diverse_conventions_amd.fused_policy import partition_rows
+    rng = np.random.default_rng(2)
+    for lists, length, period in [(6, 1, 2), (4, 63, 2), (10, 1024, 2), (7, 1025, 1), (4, 5000, 4), (2, 65471, 2)]:
+        sel = (rng.random((lists, length)) < rng.random((lists, 1))).astype(np.int32) * rng.integers(1, 9, (lists, length)).astype(np.int32)
+        sel[0] = 0
+        if lists > 1:
+            sel[1] = 5
+        index, count = partition_rows(torch.from_numpy(sel).cuda(), id_period=period)
+        index, count = index.cpu().numpy(), count.cpu().numpy()
+        for l in range(lists):
+            ids = (l % period) * length + np.arange(length)
+            zero = ids[sel[l] == 0]
+            assert count[l, 0] == len(zero) and count[l, 1] == length - len(zero)
+            assert np.array_equal(index[l, :len(zero)], zero) and np.array_equal(index[l, len(zero):], ids[sel[l] != 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n", [((5, 4), 1000), ((9, 5), 333), ((5, 5), 517), ((8, 5), 97)])
+def test_gather_tiles_evaluate_exactly_the_rows_of_their_class(shape, n):
+    """Two actors and two critics over 2 n rows; every row belongs to policy 0 or 1 by a random choice per (side, kitchen).  The
+    gathered launch (each network reads only its rows through the index lists) must give bit-for-bit what the select launch gives
+    (both candidates laid over all rows, each writing only its own): same staging bytes, same arithmetic, same draws -- on row
+    sizes that are whole 16-byte pieces (5x4, 8x5) and on ragged ones (9x5: 900 B, 5x5: 500 B) whose last piece runs into the next
+    row, with the tensor's very last row in play and canary bytes behind the observation tensor."""
+    from diverse_conventions_amd.fused_policy import GatherPlan, partition_rows, tile_select
+    W, H = shape
+    rb = W * H * 20
+    rng = np.random.default_rng(W * 31 + H)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_net(W, H, 6, ACTOR_HEAD, 1), random_net(W, H, 6, ACTOR_HEAD, 2)],
+                                           critics=[random_net(W, H, 1, CRITIC_HEAD, 3), random_net(W, H, 1, CRITIC_HEAD, 4)])
+    rows = 2 * n
+    backing = torch.full((rows * rb + 64,), 0x55, dtype=torch.int8, device="cuda")
+    obs = backing[:rows * rb].view(rows, W, H, 20)
+    obs.copy_(torch.from_numpy(((rng.random((rows, W, H, 20)) < 0.15) * rng.integers(1, 21, (rows, W, H, 20))).astype(np.int8)))
+    for trial, p1 in enumerate((0.5, 0.0, 1.0, 0.03)):
+        choice = (rng.random((2, n)) < p1).astype(np.int32)
+        if trial == 0:
+            choice[1, -1] = 1                                          # the tensor's last row belongs to the second policy ...
+        if trial == 3:
+            choice[1, -1] = 0                                          # ... or to the first
+        dchoice = torch.from_numpy(choice).cuda()
+        outs = []
+        for mode in ("select", "gather"):
+            out = dict(raw=torch.full((rows, 1), float("nan"), device="cuda"), actions=torch.full((rows,), -1, dtype=torch.int32, device="cuda"),
+                       action_logp=torch.full((rows,), float("nan"), device="cuda"), logp=torch.full((rows, 6), float("nan"), device="cuda"))
+            if mode == "select":
+                segs = []
+                for side in range(2):
+                    for c in range(2):
+                        segs += [(side * n, n, c, TILE_ACT | tile_select(c)), (side * n, n, 2 + c, tile_select(c))]
+                PolicyPlan(nets, rows, segs).forward(obs, **out, seed=9, counter=4, row_select=dchoice.view(-1))
+            else:
+                tiles = []
+                for side in range(2):
+                    for c in range(2):
+                        tiles += [(side, c, c, TILE_ACT), (side, c, 2 + c, 0)]
+                index, count = partition_rows(dchoice, id_period=2)
+                assert int(count[:, 1].sum()) == int(choice.sum())
+                GatherPlan(nets, rows, n, tiles).forward(obs, index, count, **out, seed=9, counter=4)
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy() for k, v in out.items()})
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (trial, k)
+        assert not np.isnan(outs[1]["raw"]).any() and (outs[1]["actions"] >= 0).all()
+        assert bool((backing[rows * rb:] == 0x55).all())

@@ -84,7 +84,7 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
     params = dict(layout_params["simple"], horizon=L)
     eng = OvercookedEngine(params, n, 0)
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=actors, critics=critics)
-    ro = MixedPlayRollout(eng, nets, L, main=(0, 2), partner=(1, 3), deterministic=True, rows_per_tile=32)
+    ro = MixedPlayRollout(eng, nets, L, main=(0, 2), partner=(1, 3), deterministic=True)
     g = torch.Generator(device="cuda").manual_seed(5)
     uniforms = torch.rand((2 * L, 2, n), device="cuda", generator=g)
     ro.collect(uniforms)
@@ -137,7 +137,7 @@ def test_two_collections_draw_fresh_action_noise(layout_params):
     L, n = 6, 40
     eng = OvercookedEngine(dict(layout_params["simple"], horizon=L), n, 0)
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[pick("a0."), pick("a1.")], critics=[pick("c0."), pick("c1.")])
-    ro = MixedPlayRollout(eng, nets, L, main=(0, 2), partner=(1, 3), seed=77, rows_per_tile=32)
+    ro = MixedPlayRollout(eng, nets, L, main=(0, 2), partner=(1, 3), seed=77)
     uniforms = torch.rand((2 * L, 2, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     a1 = ro.collect(uniforms).traj.actions.clone()
     lp1 = ro.logp.clone()
