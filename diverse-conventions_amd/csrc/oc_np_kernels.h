@@ -137,7 +137,7 @@ __global__ void np_step_kernel(const NpArgs a) {
 
 // ref:165-259 lossless_state_encoding for every viewer, output order (W, H, C) (envs/overcooked2_env.py:324).
 // Block = `kpb` whole kitchens (as many as give at most kNpThreads tiles; an even number when S is odd, so that every block's
-// byte range in a viewer's plane starts on a dword).  The kitchens' records are copied into LDS first (consecutive dwords: coalesced),
+// byte range in a viewer's plane starts on a dword whenever C = 5P + 10 is even; the store loop checks the address either way).  The kitchens' records are copied into LDS first (consecutive dwords: coalesced),
 // every thread then encodes ONE tile for ALL viewers from there -- the terrain / object / held-object bytes are the same for every
 // viewer, only the player slots differ (ref:221-234) -- into one staging range per viewer, and the block writes the P contiguous
 // byte ranges out 16 bytes per lane.  (The first version ran one viewer per block straight from global memory: ~11 scattered
@@ -148,7 +148,8 @@ constexpr int kNpMaxC = 5 * kMaxP + 10;             // 30 bytes per tile with fo
 __host__ __device__ inline int np_kitchens_per_block(int S) {
     int kpb = kNpThreads / S;
     if (kpb < 1) kpb = 1;                            // (S <= 255 < kNpThreads, so this does not happen)
-    if ((S & 1) && kpb > 1) kpb &= ~1;               // kpb * S * C must be a multiple of 4 bytes: C is even, so kpb * S even
+    if ((S & 1) && kpb > 1) kpb &= ~1;               // an even kitchen count per block: with C = 5P + 10 even (P = 2, 4) every block's bytes are then a
+                                                     // multiple of 4; with odd C (P = 1, 3) only of 2 -- the kernel checks each destination and stores bytes
     return kpb;
 }
 __host__ __device__ inline size_t np_encode_lds_bytes(int S, int P, int recd) {

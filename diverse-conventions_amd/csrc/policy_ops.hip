@@ -302,14 +302,16 @@ __device__ __forceinline__ int policy_gather_rows(const PolicySlot &S, const int
     if (!S.row_index || !S.row_count || t.x < 0) return 0;
     return min(max(S.row_count[2 * t.x + (t.y & 1)], 0), S.gather_len);
 }
+template <bool GATHER>
 __device__ __forceinline__ int policy_tile_blocks(const PolicySlot &S, const int4 t) {
-    if (t.w & OC_POLICY_TILE_GATHER) return (policy_gather_rows(S, t) + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (t.w & OC_POLICY_TILE_GATHER) return GATHER ? (policy_gather_rows(S, t) + kRowsPerBlock - 1) / kRowsPerBlock : 0;
     long long nr = t.y;
     if (t.x < 0 || t.x >= S.n_rows || nr <= 0) return 0;            // a bad tile contributes nothing
     if (t.x + nr > S.n_rows) nr = S.n_rows - t.x;
     return static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
 }
 
+template <bool GATHER>
 __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lane, long long &wg0, long long &wg1, int &ti, long long &tstart) {
     // Every wavefront scans the table itself, 64 entries per pass (one coalesced load + a wave prefix sum; a scalar
     // loop costs one dependent L2 round trip per entry), first for the total, then for the entry holding its first block.
@@ -317,7 +319,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         const int i = base_tile + lane;
         int4 t = make_int4(0, 0, 0, 0);
         if (i < a.n_tiles) t = a.tiles[i];
-        nb = i < a.n_tiles ? policy_tile_blocks(a.slot[0], t) : 0;             // (launches over several slots are always tile-per-workgroup)
+        nb = i < a.n_tiles ? policy_tile_blocks<GATHER>(a.slot[0], t) : 0;             // (launches over several slots are always tile-per-workgroup)
         incl = nb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -337,7 +339,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         wg1 = 0;
         for (int j = 0; j < a.tile_per_wg; ++j) {                    // (wave-uniform)
             const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
-            wg1 += policy_tile_blocks(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
+            wg1 += policy_tile_blocks<GATHER>(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
         }
     } else {
         wg1 = total * (blockIdx.x + 1) / gridDim.x;
@@ -370,7 +372,10 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
 // block like fc1 -- so a workgroup is ONE wavefront with its own network, four independent ones per CU.  For tables of short
 // segments (config 5: five 32-row blocks per segment and network), where a four-wavefront workgroup that must stay on one
 // network leaves 3 of 8 wavefront slots empty.
-template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false, bool TAIL_LDS = true>
+// GATHER: the build that also serves OC_POLICY_TILE_GATHER tiles (launches whose slot carries index lists).  A build of its own:
+// compiled into the one kernel the few extra live values cost the plain launches 7 % (48.1 -> 51.7 us for 131 070 evaluations:
+// the kernel sits at the 256-register limit of two wavefronts per SIMD).
+template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false, bool TAIL_LDS = true, bool GATHER = false>
 __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // stretch.  Everything here is wave-uniform (scalar loads of the table).
     long long wg0, wg1, tstart;
     int ti;
-    if (!policy_find_stretch(a, lane, wg0, wg1, ti, tstart)) return;
+    if (!policy_find_stretch<GATHER>(a, lane, wg0, wg1, ti, tstart)) return;
 
     // grid-dependent values: of slot 0, or (MULTI) re-derived at every tile
     int cur_slot = 0;
@@ -499,13 +504,13 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         wstart = static_cast<int>(T.L.off_b1);
     }
     const PolicySlot &S = a.slot[MULTI ? cur_slot : 0];
-    const int tnb = policy_tile_blocks(S, tile);
+    const int tnb = policy_tile_blocks<GATHER>(S, tile);
     if (tnb == 0) { ++ti; continue; }
     const long long run_end = wg1 < tstart + tnb ? wg1 : tstart + tnb;
     const int first = static_cast<int>(cur - tstart), last = static_cast<int>(run_end - tstart);   // this stretch of the tile
     // a gather tile {list, class, net, flags} evaluates the rows listed for that class of that list (oc_partition_rows: class 0's ids
     // first, class 1's behind them); its rows are staged padded to whole 16-byte pieces
-    const bool gather = (tile.w & OC_POLICY_TILE_GATHER) != 0;
+    const bool gather = GATHER && (tile.w & OC_POLICY_TILE_GATHER) != 0;
     const int32_t *gidx = gather ? S.row_index + static_cast<long long>(tile.x) * S.gather_len + ((tile.y & 1) ? policy_gather_rows(S, make_int4(tile.x, 0, 0, 0)) : 0)
                                  : nullptr;
     const long long row0 = gather ? 0 : tile.x;
@@ -1209,15 +1214,23 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
                                               oc_policy_kernel<3, false, false, true>, oc_policy_kernel<4, false, false, true>};
     static const kernel_t kernels_wave[4] = {oc_policy_kernel<1, false, false, true, false>, oc_policy_kernel<2, false, false, true, false>,
                                              oc_policy_kernel<3, false, false, true, false>, oc_policy_kernel<4, false, false, true, false>};
-    const kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+#define OC_PK(D, F, C) oc_policy_kernel<D, F, C, false, true, true>
+    static const kernel_t kernels_gather[4][2][2] = {{{OC_PK(1, false, false), OC_PK(1, false, true)}, {OC_PK(1, true, false), OC_PK(1, true, true)}},
+                                                     {{OC_PK(2, false, false), OC_PK(2, false, true)}, {OC_PK(2, true, false), OC_PK(2, true, true)}},
+                                                     {{OC_PK(3, false, false), OC_PK(3, false, true)}, {OC_PK(3, true, false), OC_PK(3, true, true)}},
+                                                     {{OC_PK(4, false, false), OC_PK(4, false, true)}, {OC_PK(4, true, false), OC_PK(4, true, true)}}};
+#undef OC_PK
+    const bool gather = !multi && s0.row_index != nullptr;
+    const kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1]
+                          : gather ? kernels_gather[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2][3] = {};                   // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : 0];
+    static size_t lds_granted[64][4][2][2][4] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : gather ? 3 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));

@@ -260,6 +260,8 @@ class OvercookedEngine:
         per_kitchen = self.size * self.channels
         if obs_global.dim() != 5 or not obs_global.is_contiguous() or kitchen_offset + n > obs_global.shape[1]:
             raise ValueError("obs_global must be a contiguous [P, N_total, W, H, C] tensor that holds the block")
+        if obs_global.shape[0] != self.num_players or tuple(obs_global.shape[2:]) != (self.width, self.height, self.channels):
+            raise ValueError(f"obs_global must be [{self.num_players}, N_total, {self.width}, {self.height}, {self.channels}]")
         dst = obs_global.data_ptr() + kitchen_offset * per_kitchen
         native.check(self._L.oc_encode_states_strided(self._handle, _ptr(records), n, ctypes.c_void_p(dst),
                                                       obs_global.shape[1] * per_kitchen, self._stream()))
@@ -280,6 +282,11 @@ class OvercookedEngine:
         native.check(self._L.oc_encode_trajectory(self._handle, _ptr(records), n, T, records.stride(0) * records.element_size(),
                                                   ctypes.c_void_p(dst), n_total * per_kitchen, 2 * n_total * per_kitchen, self._stream()))
         return obs_global
+
+    def prepare_kernels(self):
+        """Build now what is otherwise compiled on first use (time-major step kernels, fused-rollout kernels): call before a HIP-graph
+        capture that contains steps of this engine."""
+        native.check(self._L.oc_prepare_kernels(self._handle))
 
     def set_tuning(self, kitchens_per_wave=0, passes_per_flush=0, waves_per_cu=0):
         native.check(self._L.oc_set_tuning(self._handle, kitchens_per_wave, passes_per_flush, waves_per_cu))

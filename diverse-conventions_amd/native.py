@@ -41,7 +41,7 @@ SYMBOLS_ENV = [
     "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
     "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
-    "oc_import_states", "oc_import_states_checked", "oc_validate_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning",
+    "oc_import_states", "oc_import_states_checked", "oc_validate_states", "oc_num_kitchens", "oc_obs_shape", "oc_device_id", "oc_set_tuning", "oc_prepare_kernels",
     "oc_kernel_build_info", "oc_last_error", "oc_abi_version",
 ]
 # ... include/overcooked_ops.h -- policy inference, rollouts with the policies in the loop, GAE, minibatch gathers
@@ -164,6 +164,7 @@ def lib():
     L.oc_obs_shape.argtypes = [vp, ctypes.POINTER(i64 * 5)]
     L.oc_device_id.argtypes = [vp]
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
+    L.oc_prepare_kernels.argtypes = [vp]
     L.oc_exp_set_cu_budget.argtypes = [vp, ctypes.c_int32]
     fp = ctypes.c_float
     L.oc_gae_returns.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, i32, fp, fp, i32, vp]

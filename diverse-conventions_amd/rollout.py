@@ -50,6 +50,7 @@ class PairedRollout:
 
     def capture(self, warmup: int = 3):
         """Record policy GEMMs + sampling + env kernel once; replay costs one graph launch per step."""
+        self.engine.prepare_kernels()                         # nothing may compile or load a module inside the capture
         s = torch.cuda.Stream(self.engine.device)
         s.wait_stream(torch.cuda.current_stream(self.engine.device))
         with torch.cuda.stream(s):
@@ -130,6 +131,7 @@ class FusedPairedRollout:
         return self.engine.obs, self.engine.reward, self.engine.done
 
     def capture(self, warmup: int = 3):
+        self.engine.prepare_kernels()                         # nothing may compile or load a module inside the capture
         s = torch.cuda.Stream(self.engine.device)
         s.wait_stream(torch.cuda.current_stream(self.engine.device))
         with torch.cuda.stream(s):

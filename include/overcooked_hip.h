@@ -207,6 +207,12 @@ int oc_device_id(const oc_engine *e);
  * 0 keeps the current value. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
 
+/* Build NOW what is otherwise compiled on first use -- the step kernels for fresh (time-major) destinations and the
+ * K-steps-per-launch rollout kernels (hiprtc + module load, about a second each the first time, from the code-object cache
+ * afterwards).  Call it before capturing oc_step / oc_rollout* into a HIP graph: a first use inside a capture would compile and
+ * load a module there.  A build that fails is remembered and the generic kernel serves (results are identical). */
+int oc_prepare_kernels(oc_engine *e);
+
 /* Which kernel build serves this engine: "specialised for gfx950..." when the per-engine hiprtc build
  * succeeded at oc_create, otherwise the reason the generic ahead-of-time kernel is in use. */
 const char *oc_kernel_build_info(const oc_engine *e);

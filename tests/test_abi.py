@@ -128,3 +128,43 @@ int main(void) {
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
     assert out[0] == "-2" and "players" in out[1] and out[2] == "5" and out[3] == "0"
+
+
+def test_code_object_cache_checks_what_it_loads(tmp_path):
+    """The on-disk hiprtc cache: files carry a header (magic, length, checksum) and are ignored -- and rewritten -- when they do
+    not check out; a cache directory that others could have written to is not used at all."""
+    import stat
+    import subprocess
+    import sys
+    cache = tmp_path / "cache"
+    snippet = ("import sys; sys.path.insert(0, %r); from diverse_conventions_amd import native, get_base_layout_params; "
+               "print(native.jit_compile_check(get_base_layout_params(sys.argv[1], 200)))" % ROOT)
+
+    def compile_in_fresh_process(layout):
+        env = dict(os.environ, OC_JIT_CACHE=str(cache))
+        env.pop("OC_SANITIZE", None)
+        return int(subprocess.run([sys.executable, "-c", snippet, layout], check=True, capture_output=True, text=True, env=env).stdout.split()[-1])
+
+    size = compile_in_fresh_process("simple")
+    files = sorted(cache.glob("*.hsaco"))
+    assert len(files) == 1
+    good = files[0].read_bytes()
+    assert good[:8] == b"OCJIT002" and int.from_bytes(good[8:16], "little") == len(good) - 24 == size and good[24:28] == b"\x7fELF"
+    assert stat.S_IMODE(cache.stat().st_mode) == 0o700
+    # a flipped byte in the code object: the checksum refuses it, the compile runs again and rewrites the file
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x40
+    files[0].write_bytes(bytes(bad))
+    assert compile_in_fresh_process("simple") == size and files[0].read_bytes() == good
+    # a truncated file and a file with trailing bytes are refused as well
+    files[0].write_bytes(good[:-100])
+    assert compile_in_fresh_process("simple") == size and files[0].read_bytes() == good
+    files[0].write_bytes(good + b"x")
+    assert compile_in_fresh_process("simple") == size and files[0].read_bytes() == good
+    # a directory others may write to is not trusted: nothing is read from or written to it
+    os.chmod(cache, 0o770)
+    compile_in_fresh_process("unident_s")
+    assert sorted(cache.glob("*.hsaco")) == files
+    os.chmod(cache, 0o700)
+    compile_in_fresh_process("unident_s")
+    assert len(sorted(cache.glob("*.hsaco"))) == 2

@@ -268,6 +268,8 @@ def test_time_major_steps_of_a_large_small_grid_batch_use_their_own_geometry(lay
     dacts = torch.from_numpy(acts).cuda()
     eng = _engine(params, n)
     assert "kpw 32" in eng.kernel_build_info
+    eng.prepare_kernels()                        # the time-major and fused-rollout modules, ahead of their first use (idempotent)
+    eng.prepare_kernels()
     ora = oracle.OracleVecEnv(params, len(pick))
     slots = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
     rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")

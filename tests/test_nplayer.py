@@ -115,6 +115,16 @@ def test_four_player_drop_in_env_and_buffers():
         ora.step(acts[t, :, :, 0])
     assert buf.obs.shape == (T + 1, 4, n, 7, 7, 30) and np.array_equal(buf.obs[T].cpu().numpy(), ora.encode())
     assert np.array_equal(eng.encode_states(buf.records[T]).cpu().numpy(), ora.encode())       # re-featurised from the compact records
+    # an odd number of 3-player kitchens on a 7x7 grid puts the second viewer's plane at an odd byte offset (n * 49 * 25): the
+    # N-player encoder takes it (byte stores where a block's destination is not dword aligned), as oc_step / oc_observe always did
+    p3 = nplayer_params()["schelling3"]
+    e3 = OvercookedEngine(p3, 5, 0)
+    o3 = oracle.OracleVecEnv(p3, 5)
+    a3 = rng.integers(0, 6, size=(6, 3, 5)).astype(np.int32)
+    for t in range(6):
+        e3.step(torch.from_numpy(a3[t]).cuda()); o3.step(a3[t])
+    assert np.array_equal(e3.encode_states(e3.export_states()).cpu().numpy(), o3.encode())
+    e3.close()
     other = OvercookedEngine(params, n, 0)
     other.import_states(eng.export_states())
     assert torch.equal(other.observe(), buf.obs[T])
