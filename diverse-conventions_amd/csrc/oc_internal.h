@@ -9,6 +9,23 @@ struct oc_engine;
 oc_engine *oc_internal_group_engine(oc_group *g, int i);    // overcooked_engine.hip: engine i of a group (NULL if out of range)
 int oc_internal_set_cu_budget(oc_engine *e, int cus);        // size the engine's launches for a CU-masked stream (0 = whole device)
 
+// ---- the env step folded into the policy launch (policy_ops.hip: oc_policy_rollout, "one launch per training step") ----------
+// A fold group is kFoldKitchens consecutive kitchens, stepped inside the policy kernel by the wavefront whose block completed
+// the group's actions, as kFoldKitchens / kFoldKpw sub-groups of the generic step body (oc_step_kernel.h).
+namespace oc_dev { struct StepArgs; }
+constexpr int kFoldKitchens = 32, kFoldKpw = 16, kFoldPasses = 2, kFoldQN = 4;
+// Step arguments of one step of `e` with the fold geometry (its state, tables, the given action / output buffers); fresh != 0:
+// the destination is a new trajectory slot.  OC_ERR_UNSUPPORTED when this engine cannot be folded (players != 2, records too
+// large for the fold's prefetch window); *lds_bytes: LDS the body needs per wavefront.
+int oc_internal_fold_args(oc_engine *e, const void *d_actions, int8_t *d_obs, int32_t *d_reward, int32_t *d_done, oc_dev::StepArgs *out,
+                          size_t *lds_bytes);
+// Arrival counters and expected counts of the fold groups (device, engine-owned, allocated on first use; counters are zero
+// between launches), and a device-resident copy of the engine's fold step arguments with NULL action / output pointers: the
+// kernel's env call takes that template by pointer and the per-step pointers by value, which keeps a 250-byte struct out of its
+// call frames.
+int oc_internal_fold_workspace(oc_engine *e, int32_t **d_count, int32_t **d_expected, int32_t *n_groups, const oc_dev::StepArgs **d_args_template);
+void oc_internal_note_destination(oc_engine *e, const int8_t *d_obs);   // the engine's "previous destination" (store mode choice of oc_step)
+
 // Every launching entry point runs with the GPU that owns its buffers current, whatever the caller's (or torch's)
 // current device is, and puts the caller's device back on return: kernels are enqueued on streams of that GPU, and
 // CU counts / LDS opt-ins are taken from it.  Costs one hipGetDevice when the device is already current.

@@ -93,11 +93,18 @@ __device__ __forceinline__ int interact(bool act, uint32_t terr, uint32_t &t, ui
 // BATCH (!STEP only): `a` describes batch_items blocks of n_kitchens records each, item b at state +
 // b * state_batch_stride (uint4) with its planes at obs + b * obs_batch_stride (bytes): a whole gathered trajectory
 // of one peer re-featurised in one launch.
-template <bool STEP, bool ACT64, bool VEC16, int QN, int SM = SM_PLAIN, bool FUSED = false, bool BATCH = false>
-__device__ __forceinline__ void step_body(const StepArgs &a, const int block_id, const int n_blocks) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+// lds_dword_offset / lane_id: where the body's LDS block starts inside the workgroup's dynamic LDS, and the lane index, when it
+// runs as ONE wavefront of a larger workgroup (the policy kernel folds the env step of a kitchen group into its own launch,
+// policy_ops.hip); a launch of its own leaves them out.  An OFFSET, not a pointer: a generic pointer would turn every LDS access
+// into a flat instruction, which counts on vmcnt as well -- each LDS read then waits for all plane stores in flight (measured:
+// 2 us per flush group instead of 0.2).
+// COHERENT: the action buffer was filled earlier in the same launch (see load_action).
+template <bool STEP, bool ACT64, bool VEC16, int QN, int SM = SM_PLAIN, bool FUSED = false, bool BATCH = false, bool COHERENT = false>
+__device__ __forceinline__ void step_body(const StepArgs &a, const int block_id, const int n_blocks, int lds_dword_offset = 0, int lane_id = -1) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    uint32_t *const lds = lds_all + lds_dword_offset;
     const LdsView L = carve(lds, a);
-    const int lane = threadIdx.x;
+    const int lane = lane_id >= 0 ? lane_id : static_cast<int>(threadIdx.x);
     const int S = KP_S(a);
 
     // ---- software pipeline: registers hold the *next* group's state block and actions
@@ -122,8 +129,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 pa0 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0, 0));
                 pa1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0, 1));
             } else {
-                pa0 = load_action<ACT64>(a.actions, kid);
-                pa1 = load_action<ACT64>(a.actions, KP_n_kitchens(a) + kid);
+                pa0 = load_action<ACT64, COHERENT>(a.actions, kid);
+                pa1 = load_action<ACT64, COHERENT>(a.actions, KP_n_kitchens(a) + kid);
             }
         } else {
             pa0 = pa1 = A_STAY;

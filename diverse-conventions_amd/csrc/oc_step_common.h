@@ -213,8 +213,14 @@ __device__ __forceinline__ int dir_delta(int d, unsigned long long pack) {
 
 __device__ __forceinline__ int recipe_index(uint32_t obj) { return (4 * ((obj >> 8) & 0xff) + ((obj >> 16) & 0xff)) & 15; }
 
-template <bool ACT64>
+// COHERENT: the actions were written earlier in this very launch by wavefronts of other XCDs (the env step folded into the policy
+// launch): an agent-scope load, which does not trust this XCD's L2 or the CU's L1 the way a plain load does between launches.
+template <bool ACT64, bool COHERENT = false>
 __device__ __forceinline__ int load_action(const void *actions, int64_t idx) {
+    if (COHERENT) {
+        if (ACT64) return static_cast<int>(__hip_atomic_load(reinterpret_cast<const long long *>(actions) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return __hip_atomic_load(reinterpret_cast<const int *>(actions) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (ACT64) return static_cast<int>(reinterpret_cast<const long long *>(actions)[idx]);
     return reinterpret_cast<const int *>(actions)[idx];
 }

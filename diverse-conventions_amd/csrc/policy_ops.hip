@@ -50,6 +50,7 @@
 #include "overcooked_debug.h"
 #include "oc_internal.h"
 #include "policy_pack.h"
+#include "oc_step_kernel.h"     // the generic env step body: folded into the policy launch (FOLD builds)
 
 
 namespace {
@@ -62,6 +63,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
+constexpr bool kFoldByDefault = false;   // oc_policy_rollout: env step folded into the policy launch unless OC_POLICY_FOLD says otherwise
 constexpr int kMaxOut = 8;
 
 constexpr int kWaveTileBlocks = 12;    // segments shorter than this (in 32-row blocks, on average) run as wave tiles (oc_policy_plan_tiles_multi)
@@ -102,6 +104,16 @@ struct PolicyArgs {
     int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
+    // FOLD builds: the env step of slot 0's engine runs inside this launch (see fold_* below)
+    const oc_dev::StepArgs *fold_args;  // device copy of the engine's step arguments, fold geometry, without the per-step pointers ...
+    const void *fold_actions;           // ... which are these: the action buffer this launch fills, and the step's outputs
+    int8_t *fold_obs;
+    int32_t *fold_reward, *fold_done;
+    long long fold_kitchens;            // N
+    int32_t *fold_count;                // [fold_groups] arrivals so far (zero between launches)
+    const int32_t *fold_expected;       // [fold_groups] actor blocks that touch the group (fold_expected_kernel)
+    int fold_groups;                    // ceil(N / kFoldKitchens)
+    int fold_nt;                        // the env step's plane stores: 0 write-through (in place), 1 write-through non-temporal (fresh slot)
 };
 
 __device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, int slot) {
@@ -365,6 +377,83 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
     return true;
 }
 
+// ---- the env step inside the policy launch ("one launch per training step") -------------------------------------------------
+// The reference's loop is policy -> env -> policy (train/XD/xd_player.py:178-230); as two launches per step the env launch is a
+// kernel of its own that the matrix pipe waits out.  FOLD builds run it inside the policy launch, overlapped with other
+// wavefronts' MFMA work: kitchens are cut into fold groups of kFoldKitchens; every actor block, once its actions are stored and
+// fenced, adds one to the arrival counter of each group it touches, and the wavefront whose add completes a group (the counter
+// reaches the number of actor blocks touching it, counted once per rollout by fold_expected_kernel) steps that group with the
+// generic step body -- transition, encode, plane / state / reward / done stores -- using its own row-staging area as the body's
+// LDS block, at the next point where that area is free.  Nobody waits for anybody: the last arriver does the work.
+// Groups touched by rows [r0, r1] of the [2][N] row space (a block never spans more than 32 rows, so at most four).
+__device__ __forceinline__ int fold_block_groups(long long r0, long long r1, long long N, int (&g)[4]) {
+    int n = 0;
+    auto span = [&](long long ka, long long kb) {
+        for (int q = static_cast<int>(ka / kFoldKitchens); q <= static_cast<int>(kb / kFoldKitchens) && n < 4; ++q) {
+            bool seen = false;
+            for (int i = 0; i < n; ++i) seen |= g[i] == q;
+            if (!seen) g[n++] = q;
+        }
+    };
+    const long long s0 = r0 / N, s1 = r1 / N;
+    if (s0 == s1) span(r0 - s0 * N, r1 - s0 * N);
+    else { span(r0 - s0 * N, N - 1); span(0, r1 - s1 * N); }
+    return n;
+}
+
+// expected[g] = number of (actor block, group) incidences of the tile table: one thread per tile walks its blocks
+__global__ void fold_expected_kernel(const int4 *tiles, int n_tiles, long long n_rows, long long N, int32_t *expected) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles) return;
+    const int4 t = tiles[i];
+    if (!(t.w & OC_POLICY_TILE_ACT) || t.x < 0 || t.x >= n_rows || t.y <= 0) return;
+    const long long end = t.x + t.y > n_rows ? n_rows : static_cast<long long>(t.x) + t.y;
+    for (long long r = t.x; r < end; r += kRowsPerBlock) {
+        int g[4];
+        const int n = fold_block_groups(r, (r + kRowsPerBlock < end ? r + kRowsPerBlock : end) - 1, N, g);
+        for (int j = 0; j < n; ++j) atomicAdd(expected + g[j], 1);
+    }
+}
+
+// One fold group stepped by the calling wavefront: sub-groups g * kSub .. of the generic step body, one after the other, with
+// `lds` (the wavefront's row-staging area) as the body's LDS block.  A real call, not inlined: the body then gets its own register
+// allocation instead of being woven -- four copies of it -- into a kernel that sits at its 256-register limit (inlined: 2.6 KB of
+// scratch per lane, and a launch three times slower than two launches).
+struct FoldStep {                       // what changes from step to step: by value, in registers
+    const void *actions;
+    int8_t *obs;
+    int32_t *reward, *done;
+};
+// Everything but `lane` is wave-uniform, and says so (readfirstlane; the template is read through the constant address space):
+// arguments of a real call arrive in vector registers, and a step body whose "scalars" live in VGPRs -- or, as a struct copy, in
+// scratch -- ran twenty times slower than the same body as a kernel of its own.
+template <typename T> __device__ __forceinline__ T *fold_uniform(T *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<T *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __attribute__((noinline)) void fold_env_group(const oc_dev::StepArgs *tmpl, FoldStep st, int g, int nt, int lds_dword_offset, int lane, int32_t *count) {
+    oc_dev::StepArgs ea;
+    {
+        typedef __attribute__((address_space(4))) const uint32_t *const_words_t;       // scalar loads
+        const_words_t src = (const_words_t)fold_uniform(reinterpret_cast<const uint32_t *>(tmpl));
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&ea);
+        static_assert(sizeof(oc_dev::StepArgs) % 4 == 0, "StepArgs is copied word by word");
+#pragma unroll
+        for (int i = 0; i < static_cast<int>(sizeof(oc_dev::StepArgs) / 4); ++i) dst[i] = src[i];
+    }
+    ea.actions = fold_uniform(st.actions); ea.obs = fold_uniform(st.obs); ea.reward = fold_uniform(st.reward); ea.done = fold_uniform(st.done);
+    g = __builtin_amdgcn_readfirstlane(g);
+    nt = __builtin_amdgcn_readfirstlane(nt);
+    const int lds = __builtin_amdgcn_readfirstlane(lds_dword_offset);    // (an offset into the dynamic LDS, not a pointer: see step_body)
+    count = fold_uniform(count);
+    constexpr int kSub = kFoldKitchens / kFoldKpw;
+    ea.n_groups = min(ea.n_groups, (g + 1) * kSub);
+    if (nt & 1) oc_dev::generic::step_body<true, false, true, kFoldQN, oc_dev::SM_SC1_NT, false, false, true>(ea, g * kSub, 1, lds, lane);
+    else oc_dev::generic::step_body<true, false, true, kFoldQN, oc_dev::SM_SC1, false, false, true>(ea, g * kSub, 1, lds, lane);
+    if (lane == 0) count[g] = 0;                                      // every contributor has arrived: ready for the next launch
+}
+
 // MULTI: the tile table runs over several slots (grids); everything that depends on the grid is then re-derived per tile.
 // Such launches keep the conv digits in registers and fc1 in L2 (the LDS-resident tail -- biases, fc2, head -- has the same
 // layout for every grid), and map workgroup i to tile i.
@@ -375,7 +464,7 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
 // GATHER: the build that also serves OC_POLICY_TILE_GATHER tiles (launches whose slot carries index lists).  A build of its own:
 // compiled into the one kernel the few extra live values cost the plain launches 7 % (48.1 -> 51.7 us for 131 070 evaluations:
 // the kernel sits at the 256-register limit of two wavefronts per SIMD).
-template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false, bool TAIL_LDS = true, bool GATHER = false>
+template <int NDIG, bool FC1_LDS, bool CONV_LDS, bool MULTI = false, bool TAIL_LDS = true, bool GATHER = false, bool FOLD = false>
 __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const PolicyArgs a) {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
@@ -391,7 +480,10 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // stretch.  Everything here is wave-uniform (scalar loads of the table).
     long long wg0, wg1, tstart;
     int ti;
-    if (!policy_find_stretch<GATHER>(a, lane, wg0, wg1, ti, tstart)) return;
+    if (!policy_find_stretch<GATHER>(a, lane, wg0, wg1, ti, tstart)) {
+        if (!FOLD) return;
+        wg0 = wg1 = 0;                                                // no policy work: still takes its share of the untouched fold groups
+    }
 
     // grid-dependent values: of slot 0, or (MULTI) re-derived at every tile
     int cur_slot = 0;
@@ -493,6 +585,42 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         }
     };
 
+    // FOLD: groups whose counters this wavefront bumped after its last actor block (lane j < fold_n: group, the counter's value
+    // before the add -- requested there, looked at only when the staging area is next free -- and the count that completes it)
+    int fold_g = 0, fold_old = 0, fold_exp = 0, fold_n = 0;
+    long long fold_r0 = 0, fold_r1 = -1;                              // rows of the last actor block whose arrival is still to be announced
+    auto fold_drain = [&]() {                                         // call only where this wavefront's staging area is free
+        if (!FOLD || fold_n == 0) return;
+        unsigned long long mine = __ballot(lane < fold_n && fold_old + 1 == fold_exp);
+        fold_n = 0;
+        if (!mine) return;
+        // (no fence: the env body reads the actions with agent-scope loads, which do not trust this XCD's L2 -- an acquire fence here
+        // would invalidate it whole, a release fence on the writers' side write it back whole: measured 381 us per step against 62)
+        while (mine) {
+            const int j = __ffsll(static_cast<long long>(mine)) - 1;
+            mine &= mine - 1;
+            if (a.fold_nt & 2) { if (lane == 0) a.fold_count[__builtin_amdgcn_readlane(fold_g, j)] = 0; continue; }   // timing diagnostics (OC_FOLD_DEBUG=2): no env step
+            fold_env_group(a.fold_args, FoldStep{a.fold_actions, a.fold_obs, a.fold_reward, a.fold_done}, __builtin_amdgcn_readlane(fold_g, j), a.fold_nt,
+                           static_cast<int>((ldsw - lds) >> 2), lane, a.fold_count);
+            if (a.fold_nt & 4)                                        // timing diagnostics (OC_FOLD_DEBUG=4): the same group again, code now warm
+                fold_env_group(a.fold_args, FoldStep{a.fold_actions, a.fold_obs, a.fold_reward, a.fold_done}, __builtin_amdgcn_readlane(fold_g, j), a.fold_nt,
+                               static_cast<int>((ldsw - lds) >> 2), lane, a.fold_count);
+        }
+        wave_lds_sync();
+    };
+    auto fold_arrive = [&](long long r0, long long r1) {              // after a block's actions are stored
+        if (!FOLD) return;
+        int g[4];
+        const int n = fold_block_groups(r0, r1, a.fold_kitchens, g);
+        const int mine = lane == 0 ? g[0] : lane == 1 ? g[1] : lane == 2 ? g[2] : g[3];
+        if (lane < n) {
+            fold_g = mine;
+            fold_exp = a.fold_expected[mine];
+            fold_old = atomicAdd(a.fold_count + mine, 1);
+        }
+        fold_n = n;
+    };
+
   for (long long cur = wg0; cur < wg1;) {
     const int4 tile = a.tiles[ti];
     if (MULTI) {
@@ -581,6 +709,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (traced) stamp(a, wave, lane, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this block's rows have landed (LDS-DMA)
         wave_lds_sync();
+        if (FOLD && fold_r1 >= 0) { fold_arrive(fold_r0, fold_r1); fold_r1 = -1; }   // (the previous actor block's actions have completed with that wait)
         const int myrow = myrow_next;
         if (gather && (RB & 15)) {
             // the one row whose last piece could not over-read (the tensor's last row, see stage_rows_gather): its final bytes again,
@@ -727,6 +856,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         // (all at once: spreading the LDS-DMA instructions between the MFMA groups of fc2 / head was measured -- each still holds
         // the wavefront for its ~0.1 us, the time just moves there: 99.4 vs 95.2 us per cramped_room launch)
         wave_lds_sync();
+        fold_drain();                                                 // (the staging area is free: env steps of groups this wavefront completed)
         if (blk + nwaves < last) stage(blk + nwaves);
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 27);
@@ -857,13 +987,32 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
         }
         if (valid && h == 0) {
-            if (S.actions) S.actions[row] = best;
+            // FOLD: another XCD's wavefront may read the action within this launch: an agent-scope store (written through its L2)
+            if (FOLD && S.actions) __hip_atomic_store(S.actions + row, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (S.actions) S.actions[row] = best;
             if (S.action_logp) S.action_logp[row] = best_lp;
         }
+        // FOLD: this block's arrival is announced at the next landing wait (or at the end), when its action stores have completed anyway
+        if (FOLD) { fold_r0 = brow; fold_r1 = brow + min(kRowsPerBlock, nrows - blk * kRowsPerBlock) - 1; }
         if (traced) stamp(a, wave, lane, 7);
         if (traced2) stamp(a, wave, lane, 30);
     }
   }
+    if (FOLD) {
+        fold_drain();                                                 // requests of the last block but one
+        if (fold_r1 >= 0) {                                           // the last block: its actions (agent-scope stores, written through) must have completed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fold_arrive(fold_r0, fold_r1);
+            fold_drain();
+        }
+        // groups no actor block touches (a table that leaves kitchens to actions written elsewhere): stepped here, spread over all wavefronts
+        const int total_waves = gridDim.x * nwaves, me = blockIdx.x * nwaves + wave;
+        for (int g = me; g < a.fold_groups; g += total_waves)
+            if (a.fold_expected[g] == 0) {
+                fold_env_group(a.fold_args, FoldStep{a.fold_actions, a.fold_obs, a.fold_reward, a.fold_done}, g, a.fold_nt, static_cast<int>((ldsw - lds) >> 2), lane, a.fold_count);
+                wave_lds_sync();
+            }
+    }
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
@@ -875,6 +1024,7 @@ __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, u
 }
 
 unsigned long long *g_trace = nullptr;    // device buffer of the diagnostics entry below
+long long g_fold_launches = 0;            // policy launches that carried the env step (oc_debug_fold_launches)
 
 int check_shape(const oc_policy_shape *s, const char *who) {
     if (!s) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: shape is NULL", who);
@@ -1220,17 +1370,24 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
                                                      {{OC_PK(3, false, false), OC_PK(3, false, true)}, {OC_PK(3, true, false), OC_PK(3, true, true)}},
                                                      {{OC_PK(4, false, false), OC_PK(4, false, true)}, {OC_PK(4, true, false), OC_PK(4, true, true)}}};
 #undef OC_PK
+#define OC_PK(F, C) oc_policy_kernel<3, F, C, false, true, false, true>
+    static const kernel_t kernels_fold[2][2] = {{OC_PK(false, false), OC_PK(false, true)}, {OC_PK(true, false), OC_PK(true, true)}};   // (3 digits: the default)
+#undef OC_PK
+    const bool fold = a.fold_count != nullptr;
+    if (fold && (multi || wave_tiles || digits != 3 || s0.row_index))
+        return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: the folded env step needs a single-grid launch of 3-digit networks");
     const bool gather = !multi && s0.row_index != nullptr;
     const kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1]
-                          : gather ? kernels_gather[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+                          : gather ? kernels_gather[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0]
+                          : fold ? kernels_fold[fc1_lds ? 1 : 0][conv_lds ? 1 : 0] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2][4] = {};                   // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : gather ? 3 : 0];
+    static size_t lds_granted[64][4][2][2][5] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : gather ? 3 : fold ? 4 : 0];
     if (lds > 64 * 1024 && lds > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -1267,10 +1424,24 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
 
 extern "C" {
 
+// the env step folded into the launch (oc_policy_rollout): the engine's step arguments for this step and the fold groups' counters
+struct FoldParams {
+    const oc_dev::StepArgs *args;       // device template (oc_internal_fold_workspace)
+    const void *actions;
+    int8_t *obs;
+    int32_t *reward, *done;
+    long long kitchens;
+    int32_t *count;
+    const int32_t *expected;
+    int groups, nt;
+    size_t lds_need;
+};
+
 static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                                const int32_t *d_tiles, int32_t n_tiles, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len,
                                float *d_raw, int32_t *d_actions, float *d_action_logp, float *d_logp, int sample_mode, uint32_t seed,
-                               uint32_t counter, const uint32_t *d_counter, const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+                               uint32_t counter, const uint32_t *d_counter, const int32_t *d_row_select, int32_t cu_budget, void *stream,
+                               const FoldParams *fold = nullptr) {
     if (cu_budget < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: negative cu_budget");
     if (!d_tiles || n_tiles < 0 || (reinterpret_cast<uintptr_t>(d_tiles) & 15))
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_forward: d_tiles NULL or not 16-byte aligned");
@@ -1285,6 +1456,13 @@ static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packe
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.n_tiles = n_tiles;
     a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
+    if (fold) {
+        a.fold_args = fold->args; a.fold_actions = fold->actions; a.fold_obs = fold->obs; a.fold_reward = fold->reward; a.fold_done = fold->done;
+        a.fold_kitchens = fold->kitchens;
+        a.fold_count = fold->count; a.fold_expected = fold->expected; a.fold_groups = fold->groups; a.fold_nt = fold->nt;
+        if (static_cast<size_t>(staging_bytes(a.slot[0].RB)) < fold->lds_need)
+            return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: the env step's LDS block does not fit a row-staging area");
+    }
     return launch_policy(a, shape->digits, false, cu_budget, static_cast<hipStream_t>(stream));
 }
 
@@ -1349,10 +1527,47 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
     const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
     const OcDeviceScope on_device(oc_device_id(e));       // once for the whole rollout; the per-step calls then find it current
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: cannot make device %d current", oc_device_id(e));
+    // ONE launch per step: the env step folded into the policy launch (see fold_* above) wherever the shapes allow it -- 3-digit
+    // networks, no per-row selection, records and LDS block within the fold's windows.  OC_POLICY_FOLD=0 keeps the two launches.
+    FoldParams fp;
+    bool fold = false;
+    {
+        const char *env_fold = getenv("OC_POLICY_FOLD");
+        const bool want = env_fold ? (env_fold[0] && env_fold[0] != '0') : kFoldByDefault;
+        int32_t *cnt = nullptr, *expd = nullptr, groups = 0;
+        const oc_dev::StepArgs *tmpl = nullptr;
+        oc_dev::StepArgs probe;
+        if (want && T > 0 && shape->digits == 3 && !d_row_select && n_tiles > 0 &&
+            oc_internal_fold_args(e, d_actions, d_obs, d_reward, d_done, &probe, &fp.lds_need) == OC_OK &&
+            fp.lds_need <= static_cast<size_t>(staging_bytes(static_cast<int>(shp[2] * shp[3] * shp[4]))) &&
+            oc_internal_fold_workspace(e, &cnt, &expd, &groups, &tmpl) == OC_OK) {
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            // the groups' expected arrivals for THIS tile table (cheap: once per rollout call, on the stream)
+            if (hipMemsetAsync(expd, 0, static_cast<size_t>(groups) * sizeof(int32_t), st) != hipSuccess)
+                return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: cannot clear the fold counters");
+            hipLaunchKernelGGL(fold_expected_kernel, dim3(static_cast<unsigned>((n_tiles + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const int4 *>(d_tiles), n_tiles, static_cast<long long>(rows), static_cast<long long>(n), expd);
+            if (hipGetLastError() != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: fold_expected_kernel launch failed");
+            fp.args = tmpl; fp.kitchens = n;
+            fp.count = cnt; fp.expected = expd; fp.groups = groups; fp.nt = in_place ? 0 : 1;
+            if (const char *dbg = getenv("OC_FOLD_DEBUG")) fp.nt |= atoi(dbg) & ~1;      // timing diagnostics only (results then wrong by design)
+            fold = true;
+        }
+    }
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
         int8_t *obs_t = d_obs + k * slot, *obs_next = in_place ? d_obs : d_obs + (t + 1) * slot;
         int32_t *act_t = d_actions + k * rows;
+        if (fold) {
+            fp.actions = act_t; fp.obs = obs_next; fp.reward = d_reward + k * rows; fp.done = d_done + k * n;
+            if (int rc = policy_forward_impl(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, nullptr, nullptr, 0, d_values ? d_values + k * rows : nullptr,
+                                             act_t, d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
+                                             counter0 + static_cast<uint32_t>(t), nullptr, nullptr, 0, stream, &fp))
+                return rc;
+            oc_internal_note_destination(e, obs_next);
+            ++g_fold_launches;
+            continue;
+        }
         if (int rc = oc_policy_forward(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, d_values ? d_values + k * rows : nullptr, act_t,
                                        d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
                                        counter0 + static_cast<uint32_t>(t), nullptr, d_row_select ? d_row_select + t * rows : nullptr, stream))
@@ -1602,6 +1817,8 @@ int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_wa
     g_trace = nullptr;
     return OC_OK;
 }
+
+long long oc_debug_fold_launches(void) { return g_fold_launches; }
 
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action) {
     return oc_policy_uniform_from_hash(oc_policy_hash(seed, counter, row, action));

@@ -55,7 +55,7 @@ SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
 # include/overcooked_experiments.h (measured and not adopted; tools/ only) and include/overcooked_debug.h (diagnostics)
 SYMBOLS_EXPERIMENTS = ["oc_exp_cu_partition_create", "oc_exp_cu_partition_destroy", "oc_exp_policy_forward_cus", "oc_exp_set_cu_budget",
                        "oc_exp_group_policy_rollout_streams"]
-SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group", "oc_debug_trace", "oc_policy_debug_trace"]
+SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group", "oc_debug_trace", "oc_policy_debug_trace", "oc_debug_fold_launches"]
 
 
 class OcPolicyShape(ctypes.Structure):
@@ -196,6 +196,8 @@ def lib():
                                                       u32, u32, vp]
     L.oc_debug_trace.argtypes = [vp, i32, vp, i64]
     L.oc_policy_debug_trace.argtypes = [i32, vp, i64]
+    L.oc_debug_fold_launches.argtypes = []
+    L.oc_debug_fold_launches.restype = ctypes.c_longlong
     L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i32, i64, i32, i32, u32, u32, vp]
     L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, i32, u32, vp, vp]
     L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]

@@ -23,6 +23,9 @@ int oc_debug_jit_compile_group(const oc_layout_params *params, const int64_t *n_
 int oc_debug_trace(oc_engine *e, int enable, unsigned long long *host_out, int64_t max_waves);
 /* The same for the fused policy kernel (tools/trace_policy.py): [n_waves][32] stamps. */
 int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves);
+/* Policy launches so far (this process) that carried the env step inside them (oc_policy_rollout's one-launch-per-step mode): lets a
+ * test tell the folded path from its two-launch fallback. */
+long long oc_debug_fold_launches(void);
 
 #ifdef __cplusplus
 }

@@ -573,3 +573,43 @@ def test_gather_tiles_evaluate_exactly_the_rows_of_their_class(shape, n):
             assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (trial, k)
         assert not np.isnan(outs[1]["raw"]).any() and (outs[1]["actions"] >= 0).all()
         assert bool((backing[rows * rb:] == 0x55).all())
+
+
+# ------------------------------------------------------------------------------------------- one launch per training step
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,threads,k", [("simple", 37, 2), ("simple", 820, 2), ("unident_s", 45, 1), ("random1", 33, 3), ("random3", 64, 1)])
+def test_env_step_folded_into_the_policy_launch_equals_two_launches(layout, threads, k, layout_params, monkeypatch):
+    """oc_policy_rollout with the env step folded into the policy launch (OC_POLICY_FOLD=1: every actor block bumps the arrival
+    counters of the kitchen groups it touches, the wavefront that completes a group steps it inside the same launch) against the
+    two-launch path (OC_POLICY_FOLD=0), same seeds: actions, log-probs, values, observations, rewards, dones and the engines' final
+    state records must be identical -- time-major collection (fresh slots) and in-place stepping, pairing segments that do not
+    line up with the 32-kitchen fold groups, batches with one block per wavefront and with several, critics in the table."""
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, TrajectoryBuffer
+    params = layout_params[layout]
+    W, H = params["width"], params["height"]
+    G = 2 * k + 1
+    n, T = threads * G, 11
+    actors = [random_net(W, H, 6, ACTOR_HEAD, 10 + i) for i in range(k + 1)]
+    critics = [random_net(W, H, 1, CRITIC_HEAD, 20 + i) for i in range(2)]
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=critics)
+    critic_of = [[k + 1 + (g % 2) for g in range(G)], [k + 1 + ((g + 1) % 2) for g in range(G)]]
+    got = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("OC_POLICY_FOLD", fold)
+        eng = OvercookedEngine(params, n, 0)
+        eng.stagger(40)                                              # episode ends (horizon resets) inside the test's steps
+        eng.episode_control(timesteps=(torch.arange(n, device="cuda") % 7 + 190).to(torch.int32))
+        ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=critic_of, seed=3)
+        tr = TrajectoryBuffer(eng, T)
+        lp, va = torch.zeros((T, 2, n), device="cuda"), torch.zeros((T, 2, n), device="cuda")
+        before = native.lib().oc_debug_fold_launches()
+        ro.collect(tr, logp=lp, values=va)
+        obs, rew, done = ro.step(6)                                  # in place, continuing the draw counter
+        torch.cuda.synchronize()
+        assert native.lib().oc_debug_fold_launches() - before == (T + 6 if fold == "1" else 0)   # the path the variable asks for really ran
+        got[fold] = dict(tobs=tr.obs.clone(), tact=tr.actions.clone(), trew=tr.reward.clone(), tdone=tr.done.clone(), lp=lp, va=va,
+                         obs=obs.clone(), rew=rew.clone(), done=done.clone(), act=ro.actions.clone(), state=eng.export_states().clone())
+        assert int(tr.done.sum()) > 0
+        eng.close()
+    for key in got["0"]:
+        assert torch.equal(got["0"][key], got["1"][key]), key
