@@ -33,7 +33,7 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3          # us
 
 
-def run(layout, threads, k, digits=4, rows_per_tile=None, iters=50, with_torch=True):
+def run(layout, threads, k, digits=3, rows_per_tile=None, iters=50, with_torch=True):
     params = get_base_layout_params(layout, 200)
     W, H = params["width"], params["height"]
     segs = pairing_segments(threads, k)
