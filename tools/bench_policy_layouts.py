@@ -13,7 +13,7 @@ from diverse_conventions_amd import get_base_layout_params
 from diverse_conventions_amd.fused_policy import TILE_ACT, PackedNetworks, PolicyPlan
 
 plan = os.environ.get("OC_POLICY_PLAN", "default")
-DIGITS = 4
+DIGITS = 3                                                # the default: three base-256 conv weight digits
 for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("counter_circuit", 30720), ("forced_coordination", 61440), ("coordination_ring", 61440)):
     params = get_base_layout_params(layout, 200)
     W, H = params["width"], params["height"]
@@ -46,5 +46,8 @@ for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("c
     bound24 = cycles / 1024 / 2400.0
     print(json.dumps({"plan": plan, "layout": layout, "evaluations": evals, "us": round(us, 1), "issue_bound_us_at_2.4GHz": round(bound24, 1),
                       "frac_of_bound_2.4GHz": round(bound24 / us, 3), "frac_at_2.1GHz": round(bound24 * 2.4 / 2.1 / us, 3)}), flush=True)
-r = run_fused("asymmetric_advantages", 8192 // 31, 15, critics=True)
-print(json.dumps({"plan": plan, "config4_share": r}), flush=True)
+# BASELINE config 4 with the policies in the loop (asymmetric_advantages, 16 conventions in 31 pairing segments, critics): one GPU's share
+# of the 65 536 kitchens on 8, 4, 2 GPUs and the whole batch on one -- the strong-scaling prediction of DESIGN.md section 7
+for gpus in (8, 4, 2, 1):
+    r = run_fused("asymmetric_advantages", (65536 // gpus) // 31, 15, critics=True)
+    print(json.dumps({"plan": plan, "config4_share": r, "of_gpus": gpus}), flush=True)
