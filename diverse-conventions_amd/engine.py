@@ -203,7 +203,7 @@ class OvercookedEngine:
             if flat.dtype not in (torch.int32, torch.int64):
                 flat = flat.to(torch.int32)
             flat = flat.contiguous()
-            if flat.dim() < 3 or flat[0].numel() != 2 * self.num_kitchens:
+            if flat.dim() < 3 or flat[0].numel() != self.num_players * self.num_kitchens:
                 raise ValueError("rollout actions must be [T_act, P, N]")
             dt, t_act = (native.OC_ACT_I64 if flat.dtype == torch.int64 else native.OC_ACT_I32), flat.shape[0]
         obs = self.obs if obs is None else obs
@@ -272,15 +272,15 @@ class OvercookedEngine:
         [kitchen_offset, kitchen_offset+n) of every time slot of an int8 [T, P, N_total, W, H, C] tensor: one launch."""
         T, n = records.shape[0], records.shape[1]
         per_kitchen = self.size * self.channels
-        if (obs_global.dim() != 6 or not obs_global.is_contiguous() or obs_global.shape[0] != T
-                or kitchen_offset + n > obs_global.shape[2]):
+        if (obs_global.dim() != 6 or not obs_global.is_contiguous() or obs_global.shape[0] != T or obs_global.shape[1] != self.num_players
+                or kitchen_offset + n > obs_global.shape[2] or tuple(obs_global.shape[3:]) != (self.width, self.height, self.channels)):
             raise ValueError("obs_global must be a contiguous [T, P, N_total, W, H, C] tensor that holds the block")
         if records.stride(2) != 1 or records.stride(1) != records.shape[2] or records.shape[2] * records.element_size() != self.record_bytes:
             raise ValueError("every time step's records must be one contiguous [n, rec/4] block")
         n_total = obs_global.shape[2]
         dst = obs_global.data_ptr() + kitchen_offset * per_kitchen
         native.check(self._L.oc_encode_trajectory(self._handle, _ptr(records), n, T, records.stride(0) * records.element_size(),
-                                                  ctypes.c_void_p(dst), n_total * per_kitchen, 2 * n_total * per_kitchen, self._stream()))
+                                                  ctypes.c_void_p(dst), n_total * per_kitchen, self.num_players * n_total * per_kitchen, self._stream()))
         return obs_global
 
     def prepare_kernels(self):

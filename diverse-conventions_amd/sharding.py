@@ -130,11 +130,9 @@ class TrajectoryExchange:
         """The whole gathered trajectory re-featurised: int8 [T, P, world*n, W, H, C] from records [world, T, n, rec/4],
         ONE launch per peer for all T time steps (oc_encode_trajectory)."""
         world, T, n = records_all.shape[:3]
-        if engine.num_players != 2:
-            raise NotImplementedError("featurize_all re-featurises whole trajectories with oc_encode_trajectory, which is built for the "
-                                      f"2-player kitchens of the training path (this engine has {engine.num_players} players); use featurize() per step")
         if out is None:
-            out = torch.empty((T, 2, world * n, engine.width, engine.height, 20), dtype=torch.int8, device=records_all.device)
+            out = torch.empty((T, engine.num_players, world * n, engine.width, engine.height, engine.channels), dtype=torch.int8,
+                              device=records_all.device)
         for r in range(world):
             engine.encode_trajectory_into(records_all[r], out, r * n)
         return out

@@ -26,8 +26,9 @@
  *   - P = 2 players is the tuned path (the reference's training scripts and its dish-usefulness rule are 2-player): C = 5P+10
  *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
  *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a plain, separate kernel pair with the same buffers and
- *     semantics, C = 5P+10 channels; oc_rollout_fused, oc_encode_trajectory, groups and the fused
- *     policy kernel are 2-player only and return OC_ERR_UNSUPPORTED for them.  S = width*height <= 255 tiles.
+ *     semantics, C = 5P+10 channels, behind every entry point of this header: where the 2-player path has a single fused launch
+ *     (oc_rollout_fused, oc_encode_trajectory, oc_group_step) they run the equivalent sequence of plain launches, same results.
+ *     Only the fused policy kernel (overcooked_ops.h) reads 2-player observations only.  S = width*height <= 255 tiles.
  *
  * Tensor layouts (identical in meaning to the reference's exported tensors)
  *   actions  int32 or int64 [P][N]        ref: action_tensor   i32[P,N,1]   (mgr.cpp:225-229)

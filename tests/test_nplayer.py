@@ -85,8 +85,10 @@ def test_hip_vs_oracle_nplayer_batch(case):
 def test_four_player_drop_in_env_and_buffers():
     """OvercookedMadrona("multiplayer_schelling", ...) as the reference constructs it (envs/overcooked2_env.py:29): three partner
     agents, observations (N, 7, 7, 30); the time-major TrajectoryBuffer, per-kitchen episode control and state export / import /
-    re-featurisation work for any player count; the 2-player-only entry points refuse politely."""
-    from diverse_conventions_amd import EngineGroup, OvercookedEngine, OvercookedMadrona, RandomVectorAgent, TrajectoryBuffer
+    re-featurisation work for any player count, and so do tape rollouts, groups and trajectory re-featurisation (as sequences of plain
+    launches); only the built-in 2-player action stream refuses politely."""
+    from diverse_conventions_amd import (EngineGroup, OvercookedEngine, OvercookedMadrona, RandomVectorAgent, TrajectoryBuffer,
+                                         get_base_layout_params)
     from diverse_conventions_amd.native import OvercookedNativeError
     params = nplayer_params()["schelling4"]
     n, T = 64, 30
@@ -135,10 +137,36 @@ def test_four_player_drop_in_env_and_buffers():
     assert np.array_equal(tiles[0], start[0][0]) and np.array_equal(players[0], start[1][0]) and np.all(ts == 195)
     _, _, d = eng.rollout(dacts[:5, :, :, 0].to(torch.int32).contiguous(), 5)
     assert int(d.sum()) == n                                          # every kitchen reached the horizon at the fifth step
+    # what is ONE fused launch for two players is the equivalent sequence of plain launches here -- same calls, same results:
+    # a tape rollout (oc_rollout / oc_rollout_fused) against the oracle ...
+    tape = rng.integers(0, 6, size=(7, 4, n)).astype(np.int32)
+    dtape = torch.from_numpy(tape).cuda()
+    ora2 = oracle.OracleVecEnv(params, n)
+    for e, roll in ((eng, lambda e, o, r, d: e.rollout(dtape, 7, obs=o, reward=r, done=d)),
+                    (other, lambda e, o, r, d: e.rollout_fused(7, actions=dtape, obs=o, reward=r, done=d))):
+        e.reset_all()
+        o = torch.zeros((7,) + tuple(e.obs.shape), dtype=torch.int8, device="cuda")
+        r, d = torch.zeros((7, 4, n), dtype=torch.int32, device="cuda"), torch.zeros((7, n), dtype=torch.int32, device="cuda")
+        roll(e, o, r, d)
+        ora2.reset_all()
+        for t in range(7):
+            oobs, orew, odone = ora2.step(tape[t])
+            assert np.array_equal(o[t].cpu().numpy(), oobs) and np.array_equal(r[t].cpu().numpy(), orew) and np.array_equal(d[t].cpu().numpy(), odone), t
     with pytest.raises(OvercookedNativeError, match="2-player"):
-        eng.rollout_fused(3, seed=1)
-    with pytest.raises(OvercookedNativeError, match="2-player"):
-        EngineGroup([eng, other])
+        eng.rollout_fused(3, seed=1)                                  # only the built-in action stream is defined for two players
+    # ... a group that mixes player counts (one launch per engine inside, oc_group_step outside) ...
+    two = OvercookedEngine(get_base_layout_params("simple", 200), 50, 0)
+    two_solo = OvercookedEngine(get_base_layout_params("simple", 200), 50, 0)
+    grp = EngineGroup([eng, two])
+    assert "one launch per engine" in grp.build_info
+    a2 = torch.from_numpy(rng.integers(0, 6, size=(2, 50)).astype(np.int32)).cuda()
+    gobs, grew, gdone = grp.step([dtape[0], a2])
+    other.step(dtape[0]); two_solo.step(a2)
+    assert torch.equal(gobs[0], other.obs) and torch.equal(gobs[1], two_solo.obs) and torch.equal(grew[0], other.reward) and torch.equal(gdone[1], two_solo.done)
+    grp.close(); two.close(); two_solo.close()
+    # ... and a whole trajectory re-featurised from compact records (oc_encode_trajectory: T plain encode launches)
+    from diverse_conventions_amd import TrajectoryExchange
+    assert torch.equal(TrajectoryExchange().featurize_all(eng, buf.records.unsqueeze(0)), buf.obs)
     # checkpoint reload with other player counts: the device-side check knows the N-player record, a damaged checkpoint is
     # refused whole and a good one continues bit-exactly
     sd = eng.state_dict()
