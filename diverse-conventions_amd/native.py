@@ -115,11 +115,23 @@ def build(force=False, verbose=False):
     # -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs (policy_ops.hip reads them with VALU ops; the
     # accumulator-file form cost 64 v_accvgpr_read per conv position and kept the kernel at one wavefront per SIMD)
     opt = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-shared-libsan"] if SANITIZE else ["-O3"]
-    cmd = ["hipcc", "--offload-arch=gfx950"] + opt + ["-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-fPIC", "-shared", "-I", INCLUDE, "-o", LIB_PATH] + SOURCES + ["-lhiprtc"]
+    common = ["hipcc", "--offload-arch=gfx950"] + opt + ["-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-I", INCLUDE]
+    # the three translation units side by side (policy_ops.hip alone is two thirds of the time), then one link
+    objdir = os.path.join(REPO_ROOT, "build", "obj_asan" if SANITIZE else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in SOURCES]
+    cmds = [common + ["-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        for c in cmds:
+            print(" ".join(c))
+    procs = [subprocess.Popen(c) for c in cmds]
+    failed = [c for c, pr in zip(cmds, procs) if pr.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    link = ["hipcc", "--offload-arch=gfx950"] + (["-fsanitize=address,undefined", "-shared-libsan"] if SANITIZE else []) + ["-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lhiprtc"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 

@@ -10,8 +10,11 @@ CACHE=$(mktemp -d)
 trap 'rm -rf "$CACHE"' EXIT
 export OC_SANITIZE=1 OC_JIT_CACHE="$CACHE"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+# (of test_abi's per-layout compile checks a handful: each is the same host code with another table; the cache test starts
+# uninstrumented child interpreters and is left to the plain suite)
 LD_PRELOAD="$ASAN_RT" python -m pytest tests/test_abi.py tests/test_group.py tests/test_fused_policy.py tests/test_host_logic.py tests/test_layouts.py \
-    -m "not gpu" -q -p no:cacheprovider "$@"
+    -m "not gpu" -q -p no:cacheprovider \
+    -k "not code_object_cache and (not per_engine_kernel_build or simple or unident_s or six_pots or wide_hall or random3)" "$@"
 # a second process: the code objects the run above wrote are now read back from the disk cache (the read path), and the
 # process says which library it really mapped
 LD_PRELOAD="$ASAN_RT" python - <<'PY'
