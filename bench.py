@@ -115,9 +115,10 @@ def _checksum(t):
 
 
 def check_distinct_devices(idents, allow_shared=False):
-    """One rank per GPU is the contract of a multi-GPU run: two ranks that report the same device (uuid where the runtime gives
-    one, else the device index) end the run loudly -- unless the OC_BENCH_DEVICE test hook pinned them there on purpose."""
-    keys = [(d.get("uuid") or d["device_index"]) for d in idents]
+    """One rank per GPU is the contract of a multi-GPU run (one node): two ranks on the same device index end the run loudly --
+    unless the OC_BENCH_DEVICE test hook pinned them there on purpose.  (The uuids travel in the record as evidence; the check
+    itself does not lean on them: a runtime that reported one uuid for all GPUs must not take a correct 8-GPU run down.)"""
+    keys = [d["device_index"] for d in idents]
     if len(set(keys)) != len(idents) and not allow_shared:
         raise SystemExit(f"exchange: {len(idents)} ranks but only {len(set(keys))} distinct devices ({idents}); one rank per GPU is the contract")
     return len(set(keys))
