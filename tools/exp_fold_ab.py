@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""EXPERIMENT: the policies-in-the-loop rollout with two launches per step against ONE (the env step folded into the
+policy launch, OC_POLICY_FOLD=1), us per step:
+    python tools/exp_fold_ab.py [layout] [kitchens]
+Lines: fold 0 = two launches; fold 1 = one launch; debug 2 = one launch WITHOUT the env call (what the arrival bookkeeping costs;
+results wrong by design); debug 4 = the env call made twice (is a call slow because its code is cold? no: twice the time)."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch
