@@ -5,7 +5,7 @@ policy launch, OC_POLICY_FOLD=1), us per step:
 Lines: fold 0 = two launches; fold 1 = one launch; debug 2 = one launch WITHOUT the env call (what the arrival bookkeeping costs;
 results wrong by design); debug 4 = the env call made twice (is a call slow because its code is cold? no: twice the time)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, get_base_layout_params
 layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
