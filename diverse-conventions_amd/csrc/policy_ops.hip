@@ -65,6 +65,10 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 constexpr bool kFoldByDefault = false;   // oc_policy_rollout: env step folded into the policy launch unless OC_POLICY_FOLD says otherwise
 constexpr int kMaxOut = 8;
+#ifndef OC_POLICY_LATE_ROWS
+#define OC_POLICY_LATE_ROWS 1
+#endif
+constexpr bool kLateRows = OC_POLICY_LATE_ROWS != 0;   // see the network change in oc_policy_kernel
 
 constexpr int kWaveTileBlocks = 12;    // segments shorter than this (in 32-row blocks, on average) run as wave tiles (oc_policy_plan_tiles_multi)
 constexpr int kMaxSlots = 8;           // observation tensors (grids) one launch can serve: tile flags carry the slot index
@@ -101,7 +105,7 @@ struct PolicyArgs {
     uint32_t counter;
     const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
     int sample;                         // 0: argmax, 1: Gumbel-max draw
-    int lds_weight_bytes;               // LDS-resident part of the weight image (multiple of 16)
+    int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
     // FOLD builds: the env step of slot 0's engine runs inside this launch (see fold_* below)
@@ -123,6 +127,26 @@ __device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, i
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __attribute__((address_space(4))) const uint32_t *kptr_t;      // constant address space: scalar loads
+
+// The launch arguments are 1.7 KB of kernarg memory that the prologue reads a few dwords at a time, each read depending on the
+// last (tile_per_wg -> the table pointer -> the tile -> its slot's row count ...): five scalar-cache misses one after the other,
+// ~0.5 us each at the start of a launch.  Touch every 64-byte line the launch will use at once, so that the chain runs on hits.
+template <bool ALL_SLOTS>
+__device__ __forceinline__ void warm_kernarg() {
+    const kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int kSlot = static_cast<int>(sizeof(PolicySlot)), kAll = static_cast<int>(sizeof(PolicyArgs));
+    uint32_t x = 0;
+#pragma unroll
+    for (int off = 0; off < kAll; off += 64)
+        if (ALL_SLOTS || off < kSlot + 64 || off + 64 > kMaxSlots * kSlot) x |= ka[off / 4];
+    asm volatile("" ::"s"(x));
+}
+// The tile table does not change during a launch and every index into it is wave-uniform: read it with scalar loads.
+__device__ __forceinline__ int4 load_tile(const int4 *tiles, int i) {
+    const kptr_t p = (kptr_t)(tiles + i);
+    return make_int4(static_cast<int>(p[0]), static_cast<int>(p[1]), static_cast<int>(p[2]), static_cast<int>(p[3]));
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
@@ -136,7 +160,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS-DMA loads: no VGPRs, so the copy for the NEXT block can be in flight under the dense layers of this one.
 // Pieces past the end of the tensor are skipped (their rows are never stored); the one piece that straddles the
 // end goes dword by dword.
-__device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, long long brow, int lane) {
+// Returns the number of vector-memory instructions issued (for a counted vmcnt wait), or -1 on the ragged path.
+__device__ __forceinline__ int stage_rows(const PolicySlot &a, uint8_t *ldsw, long long brow, int lane) {
     const long long obs_bytes = a.n_rows * a.RB, base = brow * a.RB;
     const int n16 = 2 * a.RB;                                         // 16-byte pieces in 32 rows
     // Fast path: whole 1 KB instructions only.  The staging area is padded to a multiple of 1 KB (lds_wave_bytes), so the last
@@ -167,7 +192,7 @@ __device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, l
         default: break;
         }
 #undef OC_DMA
-        return;
+        return n_kb;
     }
     for (int it = 0; it * 64 < n16; ++it) {
         const int i = it * 64 + lane;
@@ -181,6 +206,18 @@ __device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, l
                     reinterpret_cast<uint32_t *>(ldsw + 16 * i)[q] = *reinterpret_cast<const uint32_t *>(a.obs + off + 4 * q);
         }
     }
+    return -1;
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define OC_W(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+    OC_W(1) OC_W(2) OC_W(3) OC_W(4) OC_W(5) OC_W(6) OC_W(7) OC_W(8) OC_W(9) OC_W(10) OC_W(11) OC_W(12) OC_W(13) OC_W(14) OC_W(15) OC_W(16)
+    OC_W(17) OC_W(18) OC_W(19) OC_W(20) OC_W(21) OC_W(22) OC_W(23) OC_W(24) OC_W(25) OC_W(26) OC_W(27) OC_W(28) OC_W(29) OC_W(30) OC_W(31) OC_W(32)
+#undef OC_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
 }
 
 // The same for GATHERED rows (OC_POLICY_TILE_GATHER: the rows a tile evaluates are listed in an index array -- mixed play gives
@@ -192,9 +229,10 @@ __device__ __forceinline__ void stage_rows(const PolicySlot &a, uint8_t *ldsw, l
 // takes dword-aligned addresses on both sides, tools/probes/lds_dma_align.hip); for the tensor's very last row it reads the row's
 // last 16 bytes instead and the consumer repairs those few bytes at its landing wait.  Eight instructions share one LDS base
 // (M0) through the immediate offset, which is added to BOTH addresses -- hence subtracted from the global one first.
-// Returns the row id held by lane & 31 (rows past the tile's end repeat its last row: read, never stored).
-__device__ __forceinline__ int stage_rows_gather(const PolicySlot &a, uint8_t *ldsw, const int32_t *gidx, int first, int nrows, int lane) {
+// Returns the row id held by lane & 31 (rows past the tile's end repeat its last row: read, never stored); n_instr: LDS-DMA instructions issued.
+__device__ __forceinline__ int stage_rows_gather(const PolicySlot &a, uint8_t *ldsw, const int32_t *gidx, int first, int nrows, int lane, int &n_instr) {
     const int ppr = (a.RB + 15) >> 4, total = 32 * ppr, n_kb = (total + 63) >> 6;
+    n_instr = n_kb;
     const int my = gidx[min(first + (lane & 31), nrows - 1)];
     const bool ragged = (a.RB & 15) != 0;
     const int last_row = static_cast<int>(a.n_rows - 1);
@@ -347,12 +385,30 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
             total += __builtin_amdgcn_readlane(incl, 63);
         }
     wg0 = a.tile_per_wg ? 0 : total * blockIdx.x / gridDim.x;
-    if (a.tile_per_wg) {
-        wg1 = 0;
-        for (int j = 0; j < a.tile_per_wg; ++j) {                    // (wave-uniform)
-            const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
-            wg1 += policy_tile_blocks<GATHER>(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
+    if (a.tile_per_wg == 1) {
+        const int4 t = load_tile(a.tiles, blockIdx.x);
+        wg1 = policy_tile_blocks<GATHER>(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
+    } else if (a.tile_per_wg) {
+        // several entries per workgroup (launches over several grids): lane j reads entry j -- one round trip for all of them where a
+        // scalar loop paid one per entry -- and counts its blocks against its own slot's row count; a wave sum gives the stretch
+        int nb = 0;
+        for (int c = 0; c < a.tile_per_wg; c += 64) {                 // (more than 64 entries per workgroup: not planned, but legal)
+            const int j = c + lane;
+            if (j < a.tile_per_wg) {
+                const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
+                const int sl = (t.w >> 16) & (kMaxSlots - 1);
+                long long rows_of_slot = a.slot[0].n_rows;
+                for (int q = 1; q < a.n_slots; ++q) rows_of_slot = sl == q ? a.slot[q].n_rows : rows_of_slot;
+                long long nr = t.y;                                   // (gather tiles only exist in single-grid launches)
+                if (!(t.w & OC_POLICY_TILE_GATHER) && t.x >= 0 && t.x < rows_of_slot && nr > 0) {
+                    if (t.x + nr > rows_of_slot) nr = rows_of_slot - t.x;
+                    nb += static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
+                }
+            }
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, d);
+        wg1 = __builtin_amdgcn_readfirstlane(nb);
     } else {
         wg1 = total * (blockIdx.x + 1) / gridDim.x;
     }
@@ -480,6 +536,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // stretch.  Everything here is wave-uniform (scalar loads of the table).
     long long wg0, wg1, tstart;
     int ti;
+    warm_kernarg<MULTI>();
+    stamp(a, wave, lane, 9);
     if (!policy_find_stretch<GATHER>(a, lane, wg0, wg1, ti, tstart)) {
         if (!FOLD) return;
         wg0 = wg1 = 0;                                                // no policy work: still takes its share of the untouched fold groups
@@ -622,7 +680,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     };
 
   for (long long cur = wg0; cur < wg1;) {
-    const int4 tile = a.tiles[ti];
+    const int4 tile = load_tile(a.tiles, ti);
     if (MULTI) {
         cur_slot = __builtin_amdgcn_readfirstlane((tile.w >> 16) & (kMaxSlots - 1));
         const PolicySlot &T = a.slot[cur_slot];
@@ -650,29 +708,62 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     cur = run_end;
     if (run_end == tstart + tnb) { tstart += tnb; ++ti; }
     int myrow_next = 0;                                               // gather: row id of lane & 31 in the block being staged
-    auto stage = [&](int b) {
-        if (gather) myrow_next = stage_rows_gather(S, ldsw, gidx, b * kRowsPerBlock, nrows, lane);
-        else stage_rows(S, ldsw, row0 + static_cast<long long>(b) * kRowsPerBlock, lane);
+    auto stage = [&](int b) -> int {                                  // (returns the vector-memory instructions issued, -1: unknown)
+        int n = -1;
+        if (gather) myrow_next = stage_rows_gather(S, ldsw, gidx, b * kRowsPerBlock, nrows, lane, n);
+        else n = stage_rows(S, ldsw, row0 + static_cast<long long>(b) * kRowsPerBlock, lane);
+        return n;
     };
 
     // this wavefront's first block of the stretch: in flight while (if) the weights are fetched
-    if (first + wave < last) stage(first + wave);
-    if (net != loaded_net || (MULTI && cur_slot != loaded_slot)) {
-        __syncthreads();                                              // everybody is done with the previous network
+    if (loaded_net < 0) stamp(a, wave, lane, 10);
+    // The first network of a launch.  Every wavefront of the CU wants its first rows AND its share of the weights at once: 150 KB
+    // (cramped_room, eight wavefronts) through one CU's vector-memory path, served in order, rows from HBM -- requested all together,
+    // nobody's rows are in before ~4 us and the matrix pipes idle until then.  So: the weights first (L2 hits, needed by everybody),
+    // then the rows of the first wavefront of each SIMD, then -- behind a barrier that only orders the requests -- the rows of their
+    // SIMD partners, which land under the first four's work.  (A network change later in the launch keeps the old order: wavefronts
+    // arrive there one by one and have their next rows in flight while they wait for the others.)
+    const bool reload = net != loaded_net || (MULTI && cur_slot != loaded_slot);
+    const bool first_net = kLateRows && reload && loaded_net < 0;
+    const bool late_rows = first_net && wave >= 4;
+    const bool have_rows = first + wave < last;
+    if (!first_net && have_rows) stage(first + wave);
+    if (reload) {
+        if (loaded_net < 0) stamp(a, wave, lane, 11);
+        if (loaded_net >= 0) __syncthreads();                         // everybody is done with the previous network
         const uint8_t *blob = S.packed + static_cast<size_t>(net) * S.L.total;
-        n_out = min(reinterpret_cast<const int *>(blob)[4], kMaxOut);
         // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the
         // tail from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once
-        // (a load / wait / ds_write loop cost one L2 round trip per pass).
+        // (a load / wait / ds_write loop cost one L2 round trip per pass).  Every wavefront copies a contiguous share of whole
+        // 1 KB instructions, eight of them per LDS base: a change of M0 holds the wavefront behind the copies in flight
+        // (stage_rows), and with one base per instruction the seven instructions of a wavefront went out one round trip after the
+        // other (3 us of a 6 us prologue).  The region is padded to whole KB by the host (>= 224 bytes of slack with this image layout);
+        // the lanes past its end bring the image HEADER along: the network's own output count (header word 4) is then an LDS read
+        // behind the barrier instead of a scalar load that was waited for on the spot, a round trip in front of the copy.
+        const int n16c = conv_bytes / 16, n16 = n16c + static_cast<int>(S.L.off_bh + 32 - wstart) / 16;
+        const int nkb = a.lds_weight_bytes >> 10;
         {
-            const int n16c = conv_bytes / 16, n16 = n16c + (a.lds_weight_bytes - conv_bytes) / 16;
-            for (int i0 = wave * 64; i0 < n16; i0 += blockDim.x) {
-                const int i = i0 + lane;
-                if (i < n16) {
-                    const uint8_t *src = i < n16c ? blob + S.L.off_conv + 16ll * i : blob + wstart + 16ll * (i - n16c);
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 16ll * i0), 16, 0, 0);
+            const int per = (nkb + nwaves - 1) / nwaves;
+            const int k1 = min((wave + 1) * per, nkb);
+            auto src_of = [&](int kb) -> const uint8_t * {
+                const int i = kb * 64 + lane;
+                return i < n16c ? blob + S.L.off_conv + 16ll * i : i < n16 ? blob + wstart + 16ll * (i - n16c) : blob + 16 * min(i - n16, OC_POLICY_HEADER_BYTES / 16 - 1);
+            };
+#define OC_DMAW(J) { const uint8_t *sj = src_of(g + (J)) - ((J) - 4) * 1024; __builtin_amdgcn_global_load_lds((gptr_t)sj, (lptr_t)d4, 16, ((J) - 4) * 1024, 0); }
+            for (int g = wave * per; g < k1; g += 8) {
+                uint8_t *d4 = lds + (g + 4) * 1024;
+                switch (min(k1 - g, 8)) {                             // (straight-line groups: hipcc re-writes M0 in every basic block)
+                case 8: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) OC_DMAW(7) break;
+                case 7: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) break;
+                case 6: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) break;
+                case 5: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) break;
+                case 4: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) break;
+                case 3: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) break;
+                case 2: OC_DMAW(0) OC_DMAW(1) break;
+                default: OC_DMAW(0) break;
                 }
             }
+#undef OC_DMAW
         }
         if (!CONV_LDS) {
             const v4i *src = reinterpret_cast<const v4i *>(blob + S.L.off_conv);
@@ -690,8 +781,21 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             wh = reinterpret_cast<const v4i *>(blob + S.L.off_head) + (8 * h + (col & 7));
             bh = reinterpret_cast<const float *>(blob + S.L.off_bh) + h * 4;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's share of the weight copy has landed
-        __syncthreads();                                              // the network is in LDS
+        int rows_pending = 0;                                         // instructions issued after the weight copy that need not have landed
+        if (first_net) {
+            if (!late_rows && have_rows) stage(first + wave);
+            if (nwaves > 4) asm volatile("s_barrier" ::: "memory");   // (a bare barrier: it only orders the requests -- __syncthreads() would wait for them to land)
+            if (late_rows && have_rows) rows_pending = stage(first + wave);
+        }
+        if (loaded_net < 0) stamp(a, wave, lane, 12);
+        wait_vmcnt(rows_pending);                                     // this wavefront's share of the weight copy has landed
+        if (loaded_net < 0) stamp(a, wave, lane, 13);
+        // the network is in LDS.  A bare barrier (__syncthreads() would first wait for vmcnt(0), i.e. for the rows just requested): an
+        // LDS-DMA write is complete when the issuing wavefront's vmcnt has counted it, and every wavefront has waited for its share
+        asm volatile("s_barrier" ::: "memory");
+        n_out = nkb > 0 ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds + 16 * n16 + 16))       // header word 4, copied behind the weights
+                        : reinterpret_cast<const int *>(blob)[4];                                                     // (wave tiles: nothing of the network is in LDS)
+        n_out = min(n_out, kMaxOut);
         loaded_net = net;
         loaded_slot = cur_slot;
         stamp(a, wave, lane, 1);
@@ -1332,10 +1436,11 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     //   Several grids in one launch: the four-wavefront plan with fc1 in L2 (the LDS image is then the same for every grid).
     int waves = 8;
     bool fc1_lds = false, conv_lds = true;
-    if (multi || w_conv + w_tail_small + 8 * obs1 > kLds) {
+    auto kb = [](long long b) { return (b + 32 + 1023) / 1024 * 1024; };   // the weight region is copied in whole 1 KB instructions, two header pieces behind it
+    if (multi || kb(w_conv + w_tail_small) + 8 * obs1 > kLds) {
         waves = 4;
         conv_lds = false;
-        fc1_lds = !multi && w_tail_all + 4 * obs1 <= kLds;
+        fc1_lds = !multi && kb(w_tail_all) + 4 * obs1 <= kLds;
     }
     // Two cooperative plans for the grids where eight staging areas do not fit were built and measured in round 2 -- two
     // wavefronts of a SIMD sharing one staged block and splitting its conv positions, and a conv-wavefront / dense-wavefront
@@ -1348,7 +1453,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
         int w = 0, f = 0, c = 0;
         if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
-    a.lds_weight_bytes = static_cast<int>((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small));
+    a.lds_weight_bytes = static_cast<int>(kb((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small)));
     if (wave_tiles) { waves = 1; a.lds_weight_bytes = 0; }           // one-wavefront workgroups, the whole network in L2 / registers
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
     const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;

@@ -39,6 +39,14 @@ print(f"{W}x{H} rows={rows} rows_per_tile={rpt} digits={digits}: {plan.n_tiles} 
 for i, nm in enumerate(names):
     c = t[:, i] - t0
     print(f"  {nm:34s} min {c.min():7.2f}  median {np.median(c):7.2f}  max {c.max():7.2f} us")
+pro = buf[:, [9, 10, 11, 12, 13, 1]].astype(np.float64) / 100.0
+if (pro[:, 0] > 0).all():
+    pn = ["kernel entry", "stretch found, first tile read", "first rows' DMA issued", "weight DMA issued", "weight DMA landed", "barrier passed"]
+    print("  prologue (median us after the launch's first stamp; step):")
+    prev = None
+    for i, nm in enumerate(pn):
+        c = pro[:, i] - pro[:, 0].min()
+        print(f"    {nm:34s} {np.median(c):6.2f}" + (f"   (+{np.median(pro[:, i] - pro[:, i - 1]):.2f})" if i else ""))
 d = t[:, 1:9] - t[:, 0:8]
 print("  phase durations (median us):", " ".join(f"{np.median(d[:, i]):.2f}" for i in range(8)))
 fine = buf[buf[:, 30] > 0][:, 16:31].astype(np.float64) / 100.0
