@@ -342,6 +342,35 @@ __device__ __forceinline__ v4i w1_from_l2(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
     return __builtin_bit_cast(v4i, v);
 }
 
+// One contiguous part of a network's image -> LDS, in whole 1 KB LDS-DMA instructions (lane l of instruction c moves bytes
+// [c * 1024 + 16 l, + 16)): every wavefront takes a contiguous share of the instructions and issues them eight per LDS base (M0),
+// told apart by the immediate offset like stage_rows -- a change of M0 holds the wavefront behind the copies in flight, and with
+// one base per instruction the seven instructions of a wavefront went out one round trip after the other (3 us of a 6 us
+// prologue).  The part's last instruction may run past its end: the first `last_valid` lanes carry the part, the others the
+// first 16-byte pieces of `hdr` (64: nothing is replaced and the instruction reads on into whatever follows the part).
+__device__ __forceinline__ void copy_to_lds(const uint8_t *src, uint8_t *dst, int nk, int last_valid, const uint8_t *hdr, int wave, int nwaves, int lane) {
+    const int per = (nk + nwaves - 1) / nwaves, k1 = min((wave + 1) * per, nk);
+    for (int g = wave * per; g < k1; g += 8) {
+        const uint8_t *sv = src + (g + 4) * 1024 + lane * 16;         // instruction J of the group: sv + (J - 4) * 1024
+        uint8_t *d4 = dst + (g + 4) * 1024;
+        const uint8_t *sl = sv;                                       // the same for the part's last instruction, should it need the header
+        if (last_valid < 64 && nk - 1 < g + 8)
+            sl = (lane < last_valid ? sv : hdr + 16 * min(lane - last_valid, OC_POLICY_HEADER_BYTES / 16 - 1) - (nk - 1 - g - 4) * 1024);
+#define OC_DMAW(J) { const uint8_t *sj = g + (J) == nk - 1 ? sl : sv; __builtin_amdgcn_global_load_lds((gptr_t)sj, (lptr_t)d4, 16, ((J) - 4) * 1024, 0); }
+        switch (min(k1 - g, 8)) {                                     // (straight-line groups: hipcc re-writes M0 in every basic block)
+        case 8: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) OC_DMAW(7) break;
+        case 7: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) break;
+        case 6: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) break;
+        case 5: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) break;
+        case 4: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) break;
+        case 3: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) break;
+        case 2: OC_DMAW(0) OC_DMAW(1) break;
+        default: OC_DMAW(0) break;
+        }
+#undef OC_DMAW
+    }
+}
+
 // ---- work distribution, shared by the kernels below.  The tile table lists (row range, network, flags); its 32-row
 // blocks, in table order, are split EVENLY over the workgroups of the launch (one per CU), so a workgroup owns a contiguous
 // stretch of blocks [wg0, wg1) that may run through several tiles (weights are reloaded only when the network changes along
@@ -385,30 +414,12 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
             total += __builtin_amdgcn_readlane(incl, 63);
         }
     wg0 = a.tile_per_wg ? 0 : total * blockIdx.x / gridDim.x;
-    if (a.tile_per_wg == 1) {
-        const int4 t = load_tile(a.tiles, blockIdx.x);
-        wg1 = policy_tile_blocks<GATHER>(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
-    } else if (a.tile_per_wg) {
-        // several entries per workgroup (launches over several grids): lane j reads entry j -- one round trip for all of them where a
-        // scalar loop paid one per entry -- and counts its blocks against its own slot's row count; a wave sum gives the stretch
-        int nb = 0;
-        for (int c = 0; c < a.tile_per_wg; c += 64) {                 // (more than 64 entries per workgroup: not planned, but legal)
-            const int j = c + lane;
-            if (j < a.tile_per_wg) {
-                const int4 t = a.tiles[blockIdx.x * a.tile_per_wg + j];
-                const int sl = (t.w >> 16) & (kMaxSlots - 1);
-                long long rows_of_slot = a.slot[0].n_rows;
-                for (int q = 1; q < a.n_slots; ++q) rows_of_slot = sl == q ? a.slot[q].n_rows : rows_of_slot;
-                long long nr = t.y;                                   // (gather tiles only exist in single-grid launches)
-                if (!(t.w & OC_POLICY_TILE_GATHER) && t.x >= 0 && t.x < rows_of_slot && nr > 0) {
-                    if (t.x + nr > rows_of_slot) nr = rows_of_slot - t.x;
-                    nb += static_cast<int>((nr + kRowsPerBlock - 1) / kRowsPerBlock);
-                }
-            }
+    if (a.tile_per_wg) {                                              // (several entries per workgroup as ONE vector load: measured, no faster)
+        wg1 = 0;
+        for (int j = 0; j < a.tile_per_wg; ++j) {                    // (wave-uniform)
+            const int4 t = load_tile(a.tiles, blockIdx.x * a.tile_per_wg + j);
+            wg1 += policy_tile_blocks<GATHER>(a.slot[a.n_slots > 1 ? __builtin_amdgcn_readfirstlane((t.w >> 16) & (kMaxSlots - 1)) : 0], t);
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, d);
-        wg1 = __builtin_amdgcn_readfirstlane(nb);
     } else {
         wg1 = total * (blockIdx.x + 1) / gridDim.x;
     }
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // stretch.  Everything here is wave-uniform (scalar loads of the table).
     long long wg0, wg1, tstart;
     int ti;
-    warm_kernarg<MULTI>();
+    warm_kernarg<false>();                                           // (every slot's lines, for launches over several grids: measured slower -- the misses do not all overlap)
     stamp(a, wave, lane, 9);
     if (!policy_find_stretch<GATHER>(a, lane, wg0, wg1, ti, tstart)) {
         if (!FOLD) return;
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     int wstart = static_cast<int>(FC1_LDS ? a.slot[0].L.off_fc1 : a.slot[0].L.off_b1);
     const oc_policy_layout &L0 = a.slot[0].L;
     const int conv_bytes = CONV_LDS ? static_cast<int>(L0.off_fc1 - L0.off_conv) : 0;
-    uint8_t *lds_tail = lds + conv_bytes;                                             // LDS address of image offset wstart
+    uint8_t *lds_tail = lds + ((conv_bytes + 1023) & ~1023);                          // LDS address of image offset wstart (both parts start on a KB)
     // conv weight digits: [kx*2+s][digit] x 16 bytes per lane, read from LDS per use or (when the LDS is needed for
     // large rows) held in registers; conv scale / bias per accumulator register likewise
     v4i wA[CONV_LDS ? 1 : 6][NDIG];
@@ -680,7 +691,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     };
 
   for (long long cur = wg0; cur < wg1;) {
-    const int4 tile = load_tile(a.tiles, ti);
+    // (read the way policy_find_stretch read it -- scalar for tables mapped to workgroups, vector for a table split evenly -- so that it hits the cache
+    // that read filled: the scalar and the vector L1 do not share lines)
+    const int4 tile = a.tile_per_wg ? load_tile(a.tiles, ti) : a.tiles[ti];
     if (MULTI) {
         cur_slot = __builtin_amdgcn_readfirstlane((tile.w >> 16) & (kMaxSlots - 1));
         const PolicySlot &T = a.slot[cur_slot];
@@ -719,51 +732,47 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     if (loaded_net < 0) stamp(a, wave, lane, 10);
     // The first network of a launch.  Every wavefront of the CU wants its first rows AND its share of the weights at once: 150 KB
     // (cramped_room, eight wavefronts) through one CU's vector-memory path, served in order, rows from HBM -- requested all together,
-    // nobody's rows are in before ~4 us and the matrix pipes idle until then.  So: the weights first (L2 hits, needed by everybody),
-    // then the rows of the first wavefront of each SIMD, then -- behind a barrier that only orders the requests -- the rows of their
-    // SIMD partners, which land under the first four's work.  (A network change later in the launch keeps the old order: wavefronts
-    // arrive there one by one and have their next rows in flight while they wait for the others.)
+    // nobody's rows are in before ~4 us and the matrix pipes idle until then.  So the second wavefront of each SIMD requests its rows
+    // BEHIND its share of the weights (and waits for the weights only, with a counted vmcnt): the first four start computing when
+    // 98 KB have arrived, and their SIMD partners' rows land under that work.  (One wavefront per SIMD, or a network change later in
+    // the launch: rows first -- they come from furthest away, and a wavefront that arrives early has them in flight while it waits.)
     const bool reload = net != loaded_net || (MULTI && cur_slot != loaded_slot);
-    const bool first_net = kLateRows && reload && loaded_net < 0;
-    const bool late_rows = first_net && wave >= 4;
+    const bool late_rows = kLateRows && reload && loaded_net < 0 && nwaves > 4 && wave >= 4;
     const bool have_rows = first + wave < last;
-    if (!first_net && have_rows) stage(first + wave);
-    if (reload) {
+    int rows_pending = 0;                                             // row instructions issued behind the weight copy: they need not have landed at the barrier
+    const uint8_t *blob = nullptr;
+    int tail_bytes = 0;
+    bool weights_in_lds = false;
+    int hdr_n_out = 0;
+    // (two passes through ONE copy of the row-staging code -- early rows, weights, late rows; a second inlined copy of stage_rows
+    // costs the 256-register build SGPR spills it has no lane left for)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (have_rows && late_rows == (pass == 1)) {
+            const int n = stage(first + wave);
+            if (pass == 1) rows_pending = n;
+        }
+        if (pass == 1 || !reload) continue;
         if (loaded_net < 0) stamp(a, wave, lane, 11);
         if (loaded_net >= 0) __syncthreads();                         // everybody is done with the previous network
-        const uint8_t *blob = S.packed + static_cast<size_t>(net) * S.L.total;
+        blob = S.packed + static_cast<size_t>(net) * S.L.total;
+        if (a.lds_weight_bytes == 0) hdr_n_out = reinterpret_cast<const int *>(blob)[4];   // (wave tiles: requested here, used behind the barrier)
         // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the
-        // tail from fc1 (or, when fc1 does not fit, from b1) to the end.  LDS-DMA: every piece is in flight at once
-        // (a load / wait / ds_write loop cost one L2 round trip per pass).  Every wavefront copies a contiguous share of whole
-        // 1 KB instructions, eight of them per LDS base: a change of M0 holds the wavefront behind the copies in flight
-        // (stage_rows), and with one base per instruction the seven instructions of a wavefront went out one round trip after the
-        // other (3 us of a 6 us prologue).  The region is padded to whole KB by the host (>= 224 bytes of slack with this image layout);
-        // the lanes past its end bring the image HEADER along: the network's own output count (header word 4) is then an LDS read
-        // behind the barrier instead of a scalar load that was waited for on the spot, a round trip in front of the copy.
-        const int n16c = conv_bytes / 16, n16 = n16c + static_cast<int>(S.L.off_bh + 32 - wstart) / 16;
-        const int nkb = a.lds_weight_bytes >> 10;
-        {
-            const int per = (nkb + nwaves - 1) / nwaves;
-            const int k1 = min((wave + 1) * per, nkb);
-            auto src_of = [&](int kb) -> const uint8_t * {
-                const int i = kb * 64 + lane;
-                return i < n16c ? blob + S.L.off_conv + 16ll * i : i < n16 ? blob + wstart + 16ll * (i - n16c) : blob + 16 * min(i - n16, OC_POLICY_HEADER_BYTES / 16 - 1);
-            };
-#define OC_DMAW(J) { const uint8_t *sj = src_of(g + (J)) - ((J) - 4) * 1024; __builtin_amdgcn_global_load_lds((gptr_t)sj, (lptr_t)d4, 16, ((J) - 4) * 1024, 0); }
-            for (int g = wave * per; g < k1; g += 8) {
-                uint8_t *d4 = lds + (g + 4) * 1024;
-                switch (min(k1 - g, 8)) {                             // (straight-line groups: hipcc re-writes M0 in every basic block)
-                case 8: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) OC_DMAW(7) break;
-                case 7: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) OC_DMAW(6) break;
-                case 6: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) OC_DMAW(5) break;
-                case 5: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) OC_DMAW(4) break;
-                case 4: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) OC_DMAW(3) break;
-                case 3: OC_DMAW(0) OC_DMAW(1) OC_DMAW(2) break;
-                case 2: OC_DMAW(0) OC_DMAW(1) break;
-                default: OC_DMAW(0) break;
-                }
-            }
-#undef OC_DMAW
+        // tail from fc1 (or, when fc1 does not fit, from b1) to the end, each padded to whole KB in LDS.  LDS-DMA: every piece is
+        // in flight at once (a load / wait / ds_write loop cost one L2 round trip per pass); see copy_to_lds.  The lanes past the
+        // tail's end bring the image HEADER along: the network's own output count (header word 4) is then an LDS read behind the
+        // barrier instead of a scalar load that was waited for on the spot, one more round trip in front of the copy.
+        tail_bytes = static_cast<int>(S.L.off_bh + 32 - wstart);
+        weights_in_lds = a.lds_weight_bytes > 0;
+        if (weights_in_lds) {
+            // (the wavefront index behind an empty asm: everything copy_to_lds derives from it is then computed here, where it is used --
+            // hoisted out of the tile loop those values stayed live through the block loop, as SGPRs spilled to lanes of one more VGPR
+            // than the 256-register build has to spare)
+            int wv = wave;
+            asm volatile("" : "+s"(wv));
+            if (CONV_LDS) copy_to_lds(blob + S.L.off_conv, lds, (conv_bytes + 1023) >> 10, 64, blob, wv, nwaves, lane);   // (its last KB runs on into the image: read, never used)
+            const int nk = (tail_bytes + 32 + 1023) >> 10;
+            copy_to_lds(blob + wstart, lds_tail, nk, (tail_bytes >> 4) - (nk - 1) * 64, blob, wv, nwaves, lane);
         }
         if (!CONV_LDS) {
             const v4i *src = reinterpret_cast<const v4i *>(blob + S.L.off_conv);
@@ -781,20 +790,16 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             wh = reinterpret_cast<const v4i *>(blob + S.L.off_head) + (8 * h + (col & 7));
             bh = reinterpret_cast<const float *>(blob + S.L.off_bh) + h * 4;
         }
-        int rows_pending = 0;                                         // instructions issued after the weight copy that need not have landed
-        if (first_net) {
-            if (!late_rows && have_rows) stage(first + wave);
-            if (nwaves > 4) asm volatile("s_barrier" ::: "memory");   // (a bare barrier: it only orders the requests -- __syncthreads() would wait for them to land)
-            if (late_rows && have_rows) rows_pending = stage(first + wave);
-        }
+    }
+    if (reload) {
         if (loaded_net < 0) stamp(a, wave, lane, 12);
         wait_vmcnt(rows_pending);                                     // this wavefront's share of the weight copy has landed
         if (loaded_net < 0) stamp(a, wave, lane, 13);
         // the network is in LDS.  A bare barrier (__syncthreads() would first wait for vmcnt(0), i.e. for the rows just requested): an
         // LDS-DMA write is complete when the issuing wavefront's vmcnt has counted it, and every wavefront has waited for its share
         asm volatile("s_barrier" ::: "memory");
-        n_out = nkb > 0 ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds + 16 * n16 + 16))       // header word 4, copied behind the weights
-                        : reinterpret_cast<const int *>(blob)[4];                                                     // (wave tiles: nothing of the network is in LDS)
+        n_out = weights_in_lds ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds_tail + tail_bytes + 16))   // header word 4, copied behind the tail
+                               : hdr_n_out;                                                                                   // (wave tiles: nothing of the network is in LDS)
         n_out = min(n_out, kMaxOut);
         loaded_net = net;
         loaded_slot = cur_slot;
@@ -1436,11 +1441,11 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     //   Several grids in one launch: the four-wavefront plan with fc1 in L2 (the LDS image is then the same for every grid).
     int waves = 8;
     bool fc1_lds = false, conv_lds = true;
-    auto kb = [](long long b) { return (b + 32 + 1023) / 1024 * 1024; };   // the weight region is copied in whole 1 KB instructions, two header pieces behind it
-    if (multi || kb(w_conv + w_tail_small) + 8 * obs1 > kLds) {
+    auto kb = [](long long b) { return (b + 1023) / 1024 * 1024; };   // either part is copied in whole 1 KB instructions, two header pieces behind the tail
+    if (multi || kb(w_conv) + kb(w_tail_small + 32) + 8 * obs1 > kLds) {
         waves = 4;
         conv_lds = false;
-        fc1_lds = !multi && kb(w_tail_all) + 4 * obs1 <= kLds;
+        fc1_lds = !multi && kb(w_tail_all + 32) + 4 * obs1 <= kLds;
     }
     // Two cooperative plans for the grids where eight staging areas do not fit were built and measured in round 2 -- two
     // wavefronts of a SIMD sharing one staged block and splitting its conv positions, and a conv-wavefront / dense-wavefront
@@ -1453,7 +1458,9 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
         int w = 0, f = 0, c = 0;
         if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
     }
-    a.lds_weight_bytes = static_cast<int>(kb((conv_lds ? w_conv : 0) + (fc1_lds ? w_tail_all : w_tail_small)));
+    a.lds_weight_bytes = static_cast<int>((conv_lds ? kb(w_conv) : 0) + kb((fc1_lds ? w_tail_all : w_tail_small) + 32));
+    if ((fc1_lds ? w_tail_all : w_tail_small) % 1024 > 1024 - 32)     // (the two header pieces ride in the tail's last 1 KB instruction; 544 with this image layout)
+        return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: image layout leaves no room for the header behind the LDS tail");
     if (wave_tiles) { waves = 1; a.lds_weight_bytes = 0; }           // one-wavefront workgroups, the whole network in L2 / registers
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
     const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;

@@ -15,7 +15,10 @@ CSRC = os.path.join(_HERE, "csrc")
 #   OC_SANITIZE=1 LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 \
 #       python -m pytest tests -m "not gpu" -k "abi or plan or planner or jit"          (tools/run_sanitized.sh)
 SANITIZE = os.environ.get("OC_SANITIZE", "0") not in ("", "0")
-LIB_PATH = os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip.so")
+# OC_LIB_PATH=<file>: load that build of the library instead (A/B measurements of two builds in one GPU call, tools/ab_builds.sh);
+# build() then leaves it alone
+LIB_OVERRIDE = os.environ.get("OC_LIB_PATH", "")
+LIB_PATH = LIB_OVERRIDE or os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
 HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h")]
@@ -100,6 +103,10 @@ def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU.  Output stays in-tree (csrc/liboc_hip.so)."""
     newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [KERNEL_HEADER, KERNEL_COMMON, KERNEL_BODY] +
                  [os.path.join(INCLUDE, h) for h in ("overcooked_hip.h", "overcooked_ops.h", "overcooked_experiments.h", "overcooked_debug.h")])
+    if LIB_OVERRIDE:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"OC_LIB_PATH={LIB_PATH} does not exist")
+        return LIB_PATH
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     # the kernel headers are also embedded as text: oc_create() / oc_group_create() re-compile them with hiprtc
