@@ -327,9 +327,14 @@ def main():
     t_act = 64
     actions = torch.randint(0, 6, (t_act, 2, n), generator=gen, device="cuda", dtype=torch.int32)
 
+    # the bracket barrier: an all-reduce of one pre-allocated element (nobody's completes before everybody has entered) followed by
+    # the device sync -- 20 us with one RCCL rank where dist.barrier(), which allocates its own tensor, takes 28
+    # (tools/exp_barrier_cost.py); a 20-step timed region is 270 us
+    bar_token = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu") if use_dist else None
+
     def barrier():
         if use_dist:
-            dist.barrier()
+            dist.all_reduce(bar_token)
         torch.cuda.synchronize()
 
     # W untimed warm-up steps; the last of them goes through the timed entry point, so that the timed region is not the first
