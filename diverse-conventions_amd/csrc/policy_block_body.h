@@ -1,0 +1,341 @@
+// policy_block_body.h -- one 32-row block of oc_policy_kernel (policy_ops.hip), included TWICE inside the kernel: as the body of the
+// loop over a wavefront's own blocks (OC_BLOCK_COOP 0) and, inside a do { } while (false), as the cooperative block that the
+// wavefronts of a group share (OC_BLOCK_COOP 1; see "cooperative blocks" in the kernel).  Two textual instances rather than a runtime
+// flag or a generic lambda: with a position stride the compiler cannot see is 1 the ordinary blocks ran 5-10 % slower, and as a
+// lambda called from two places the gather build spilled 96 VGPRs (mixed play 2.5x slower).  `continue` ends the block in both.
+// No include guard; everything it names is a local of the kernel.
+        constexpr bool cp = OC_BLOCK_COOP != 0;
+        const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
+        const bool traced = a.trace != nullptr && !trace_done;       // diagnostics: this wavefront's first block of the launch
+        const bool traced2 = a.trace != nullptr && trace_done && !trace2_done;   // ... and, finer, its second
+        if (trace_done) trace2_done = true;
+        trace_done = true;
+        if (traced2) stamp(a, wave, lane, 16);
+        if (traced) stamp(a, wave, lane, 2);
+        if (!cp || leader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's rows have landed (LDS-DMA; a cooperative block: the leader's request)
+        if (cp) {
+            asm volatile("s_barrier" ::: "memory");                   // the leaders' rows are in (a bare barrier: see the network barrier above)
+            if (!in_coop) { __syncthreads(); __syncthreads(); continue; }   // (the two barriers of the hand-over below)
+            rowp = lds + a.lds_weight_bytes + static_cast<size_t>(grp * gsz) * a.lds_wave_bytes + col * RS + 16 * h;   // the leader's staging area
+        }
+        wave_lds_sync();
+        if (FOLD && fold_r1 >= 0) { fold_arrive(fold_r0, fold_r1); fold_r1 = -1; }   // (the previous actor block's actions have completed with that wait)
+        const int myrow = myrow_next;
+        if (gather && (RB & 15)) {
+            // the one row whose last piece could not over-read (the tensor's last row, see stage_rows_gather): its final bytes again,
+            // dword by dword -- at most one row per launch, so this branch is all but never taken
+            const bool fix = h == 0 && col + blk * kRowsPerBlock < nrows && myrow == static_cast<int>(S.n_rows - 1);
+            if (__ballot(fix)) {
+                if (fix) {
+                    const int tail0 = (RB >> 4) << 4;
+                    const uint32_t *sp = reinterpret_cast<const uint32_t *>(S.obs + static_cast<long long>(myrow) * RB + tail0);
+                    uint32_t *dp = reinterpret_cast<uint32_t *>(ldsw + col * RS + tail0);
+                    for (int q = 0; q < (RB & 15) >> 2; ++q) dp[q] = sp[q];
+                }
+                wave_lds_sync();
+            }
+        }
+        if (traced) stamp(a, wave, lane, 3);
+        if (traced2) stamp(a, wave, lane, 17);
+        // A tile with a select code skips the blocks none of whose rows it would write (mixed play: the stretch of
+        // kitchens already forced onto the other policy costs this network nothing).
+        if (((flags >> 8) & 0xff) && S.row_select) {
+            const int want = ((flags >> 8) & 0xff) - 1;
+            const bool mine = col + blk * kRowsPerBlock < nrows && S.row_select[brow + col] == want;
+            if (__ballot(mine) == 0) {
+                if (blk + nwaves < last) stage(blk + nwaves);         // (tiles with a select code have no cooperative block)
+                continue;
+            }
+        }
+
+        // The position loop is software-pipelined by hand: one wavefront per SIMD issues in order, so anything
+        // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
+        // p run, the VALU turns the conv accumulators of position p+1 into fc1 operands (needed one iteration
+        // later, so nothing waits for them), and the LDS reads for position p+2 are in flight.
+        // (a cooperative block: this wavefront's positions are p_first, p_first + p_step, ...; otherwise all of them)
+        const int p_first = cp ? member : 0, p_step = cp ? gsz : 1;
+        int pi = 0, xq = 0, yq = 0;                                   // position whose B operands `bfr` holds
+        auto advance1 = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
+        auto advance = [&]() { for (int i = 0; i < p_step; ++i) advance1(); };
+        for (int i = 0; i < p_first; ++i) advance1();
+        v4i bfr[6];
+        read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        v16i acc[NDIG];
+        conv(acc, bfr);                                               // the first position
+        advance();
+        read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        v16f h1[2];                                                   // accumulators start at the bias (a cooperative block: the leader's do)
+        {
+            const v4f *bq = reinterpret_cast<const v4f *>(b1);
+            const bool with_bias = !cp || member == 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[m][r] = with_bias ? bq[m * 8 + (r >> 2)][r & 3] : 0.f;
+        }
+        if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
+        // wave tiles: the dense layers' biases come from L2 -- requested here, used after the position loop
+        v4f b2q[TAIL_LDS ? 1 : 8], bhq = {0.f, 0.f, 0.f, 0.f};
+        if (!TAIL_LDS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b2q[TAIL_LDS ? 0 : i] = reinterpret_cast<const v4f *>(b2)[(i >> 2) * 8 + (i & 3)];
+            bhq = *reinterpret_cast<const v4f *>(bh);
+        }
+        // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
+        auto make_operand = [&](v4i (&dst)[3][2], int j) {            // pair j = accumulator registers 2j, 2j + 1
+            int hi, mid, lo;
+            float x0, x1;
+            combine_pair(acc, 2 * j, x0, x1);
+            split_pair(x0, x1, hi, mid, lo);
+            dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = mid; dst[2][j >> 2][j & 3] = lo;
+        };
+        v4i xb[3][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) make_operand(xb, j);
+        if (traced2) stamp(a, wave, lane, 19);
+
+        // fc1 fragments of a position [piece][k-group][out half].  They are requested one position ahead, into the registers
+        // the MFMAs of the current position have just read, so an L2 round trip (fc1 not LDS-resident) has the operand
+        // conversion and the next conv to land in.
+        v4i w1r[3][2][2];
+        auto load_w1 = [&](int p) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo)
+                        w1r[q][g][mo] = FC1_LDS ? w1l[(p * 12 + (q * 2 + g) * 2 + mo) * 64]
+                                                : w1_from_l2(w1g, lane16, p, (q * 2 + g) * 2 + mo);
+        };
+        load_w1(p_first);
+        // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x six piece products x two
+        // output halves.  Unless it is the last, the next position's operand is built around them: the second k-group's
+        // registers (pairs 4..7) into spare registers next to the first group's MFMAs, the first group's (pairs 0..3) in place
+        // once its MFMAs have issued.
+        auto position = [&](int p, auto last_tag) {
+            constexpr bool kLast = decltype(last_tag)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!kLast) conv(acc, bfr);                               // conv of position p+1
+            __builtin_amdgcn_sched_barrier(0);
+            if (!kLast) {
+                advance();
+                read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v4i nb1[3];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                h1[0] = mfma_bf16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
+                h1[1] = mfma_bf16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
+                if (!kLast && t < 4) {
+                    int hi, mid, lo;
+                    float x0, x1;
+                    combine_pair(acc, 8 + 2 * t, x0, x1);
+                    split_pair(x0, x1, hi, mid, lo);
+                    nb1[0][t] = hi; nb1[1][t] = mid; nb1[2][t] = lo;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                h1[0] = mfma_bf16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
+                h1[1] = mfma_bf16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
+            }
+            if (!kLast) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_w1(p + p_step);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) make_operand(xb, t);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xb[q][1] = nb1[q];
+            }
+            if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
+        };
+        {
+            int p = p_first;
+            for (; p + p_step < P; p += p_step) position(p, std::false_type());
+            position(p, std::true_type());
+        }
+        if (cp) {
+            // the hand-over: partial sums of the other members -> the leader, through the members' own staging areas (idle: the stretch
+            // is over for them), [register quad][lane] 16 bytes each
+            if (member != 0) {
+                v4f *pp = reinterpret_cast<v4f *>(ldsw) + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pp[i * 64] = v4f{h1[i >> 2][4 * (i & 3)], h1[i >> 2][4 * (i & 3) + 1], h1[i >> 2][4 * (i & 3) + 2], h1[i >> 2][4 * (i & 3) + 3]};
+            }
+            __syncthreads();
+            if (member == 0)
+                for (int m = 1; m < gsz; ++m) {
+                    const v4f *qq = reinterpret_cast<const v4f *>(lds + a.lds_weight_bytes + static_cast<size_t>(grp * gsz + m) * a.lds_wave_bytes) + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const v4f t = qq[i * 64];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) h1[i >> 2][4 * (i & 3) + j] += t[j];
+                    }
+                }
+            __syncthreads();                                          // (the members' areas are theirs again)
+            if (member != 0) continue;
+        }
+        if (traced) stamp(a, wave, lane, 4);
+        if (traced2) stamp(a, wave, lane, 26);
+        v16f h2[2], out, out2;
+        {
+            const v4f *bq = reinterpret_cast<const v4f *>(b2);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h2[m][r] = TAIL_LDS ? bq[m * 8 + (r >> 2)][r & 3] : b2q[TAIL_LDS ? 0 : m * 4 + (r >> 2)][r & 3];
+            const v4f bhv = TAIL_LDS ? *reinterpret_cast<const v4f *>(bh) : bhq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { out[r] = r < 4 ? bhv[r] : 0.f; out2[r] = 0.f; }
+        }
+        // the staging area is free: start the copy of this wavefront's next block under the dense layers
+        // (all at once: spreading the LDS-DMA instructions between the MFMA groups of fc2 / head was measured -- each still holds
+        // the wavefront for its ~0.1 us, the time just moves there: 99.4 vs 95.2 us per cramped_room launch)
+        wave_lds_sync();
+        fold_drain();                                                 // (the staging area is free: env steps of groups this wavefront completed)
+        {
+            const int nxt = cp ? -1 : blk + nwaves < last_full ? blk + nwaves : leader ? last_full + grp : -1;   // (a leader's last prefetch: the shared block)
+            if (nxt >= 0) stage(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (traced2) stamp(a, wave, lane, 27);
+
+        // ---- fc2: h2^T[n2][row] = b2 + W2 relu(h1): four k-groups (input half kg >> 1, registers 8 (kg & 1) ..) ----
+        // the operand pieces of k-group kg + 1 are built under the MFMAs of k-group kg
+        auto split_group = [&](const v16f &v, int g, v4i (&dst)[3]) {  // relu + split of registers 8g .. 8g + 7
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int hi, mid, lo;
+                split_pair(relu(v[8 * g + 2 * j]), relu(v[8 * g + 2 * j + 1]), hi, mid, lo);
+                dst[0][j] = hi; dst[1][j] = mid; dst[2][j] = lo;
+            }
+        };
+        // weight fragments: from LDS one k-group ahead; from L2 (wave tiles) all four k-groups at once, and the head's as well,
+        // half-way through fc2 -- twelve MFMAs (0.2 us) do not cover an L2 round trip
+        constexpr int WB = TAIL_LDS ? 2 : 4;                          // fragment buffers
+        v4i whr[WB][3];
+        auto load_wh = [&](int kg) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) whr[kg % WB][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
+        };
+        {
+            v4i hb[2][3];                                             // [parity of kg][piece]
+            v4i w2r[WB][3][2];                                        // [kg % WB][piece][out half]
+            auto load_w2 = [&](int kg) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo) w2r[kg % WB][q][mo] = w2[((q * 4 + kg) * 2 + mo) * 64];
+            };
+            load_w2(0);
+            if (!TAIL_LDS) {
+#pragma unroll
+                for (int kg = 1; kg < 4; ++kg) load_w2(kg);
+            }
+            split_group(h1[0], 0, hb[0]);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                if (TAIL_LDS && kg + 1 < 4) load_w2(kg + 1);
+                if (!TAIL_LDS && kg == 2) {                           // (the first two k-groups' fragments have been consumed)
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) load_wh(k2);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    h2[0] = mfma_bf16(w2r[kg % WB][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
+                    h2[1] = mfma_bf16(w2r[kg % WB][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
+                }
+                if (kg + 1 < 4) split_group(h1[(kg + 1) >> 1], (kg + 1) & 1, hb[(kg + 1) & 1]);
+            }
+        }
+        if (traced) stamp(a, wave, lane, 5);
+        if (traced2) stamp(a, wave, lane, 28);
+        // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; two accumulators so consecutive MFMAs do not wait for each other ----
+        {
+            v4i gb[2][3];
+            if (TAIL_LDS) load_wh(0);
+            split_group(h2[0], 0, gb[0]);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                if (TAIL_LDS && kg + 1 < 4) load_wh(kg + 1);
+#pragma unroll
+                for (int t = 0; t < 6; t += 2) {
+                    out = mfma_bf16(whr[kg % WB][kTermW[t]], gb[kg & 1][kTermX[t]], out);
+                    out2 = mfma_bf16(whr[kg % WB][kTermW[t + 1]], gb[kg & 1][kTermX[t + 1]], out2);
+                }
+                if (kg + 1 < 4) split_group(h2[(kg + 1) >> 1], (kg + 1) & 1, gb[(kg + 1) & 1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] += out2[r];
+        }
+        if (traced) stamp(a, wave, lane, 6);
+        if (traced2) stamp(a, wave, lane, 29);
+
+        // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
+        //      work on their own actions and meet through three lane exchanges ----
+        const long long row = gather ? myrow : brow + col;
+        bool valid = (blk * kRowsPerBlock + col) < nrows;
+        const int sel = (flags >> 8) & 0xff;                          // OC_POLICY_TILE_SELECT(v): only rows with row_select == v
+        if (sel && S.row_select && valid) valid = S.row_select[row] == sel - 1;
+        if (!(flags & OC_POLICY_TILE_ACT)) {
+            if (valid && S.raw) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * h + r < n_out) S.raw[row * n_out + 4 * h + r] = out[r];
+            }
+            continue;
+        }
+        // actor: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80), then argmax (mode) or
+        // a Gumbel-max draw
+        // (branch-free over the lane's four outputs: the ones past n_out count as -inf -- exp gives 0, the key never wins -- so
+        // the lane halves, which own different numbers of valid outputs, run one straight instruction stream)
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = 4 * h + r < n_out ? out[r] : -INFINITY;
+        float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += __expf(x[r] - mx);          // v_exp_f32: relative error ~1e-7 on arguments <= 0
+        sum += __shfl_xor(sum, 32);
+        const float lse = mx + __logf(sum);                          // sum in [1, n_out]: absolute error ~2e-7
+        int best = 0;
+        float best_key = -INFINITY, best_lp = 0.f;
+        float lps[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * h + r;
+            const float lp = x[r] - lse;
+            float key = lp;
+            if (a.sample) {                                           // the noise needs no more than the fast logarithm
+                const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), i));
+                key = lp - __logf(-__logf(u));
+            }
+            const bool wins = key > best_key;
+            best_key = wins ? key : best_key; best = wins ? i : best; best_lp = wins ? lp : best_lp;
+            lps[r] = lp;
+        }
+        if (valid && S.logp) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * h + r < n_out) S.logp[row * n_out + 4 * h + r] = lps[r];
+        }
+        {
+            const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
+            const int obest = __shfl_xor(best, 32);
+            if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
+        }
+        if (valid && h == 0) {
+            // FOLD: another XCD's wavefront may read the action within this launch: an agent-scope store (written through its L2)
+            if (FOLD && S.actions) __hip_atomic_store(S.actions + row, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (S.actions) S.actions[row] = best;
+            if (S.action_logp) S.action_logp[row] = best_lp;
+        }
+        // FOLD: this block's arrival is announced at the next landing wait (or at the end), when its action stores have completed anyway
+        if (FOLD) { fold_r0 = brow; fold_r1 = brow + min(kRowsPerBlock, nrows - blk * kRowsPerBlock) - 1; }
+        if (traced) stamp(a, wave, lane, 7);
+        if (traced2) stamp(a, wave, lane, 30);

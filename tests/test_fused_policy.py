@@ -313,9 +313,54 @@ def test_kernel_other_grids_vs_oracle(W, H):
 
 
 @pytest.mark.gpu
-def test_multi_grid_launch_equals_per_grid_launches():
+@pytest.mark.parametrize("W,H,blocks", [(9, 5, 5), (9, 5, 6), (5, 5, 5), (8, 5, 9), (9, 5, 1)])
+def test_cooperative_blocks(W, H, blocks, monkeypatch):
+    """A stretch of 4 k + 1 (4 k + 2) blocks on a four-wavefront workgroup: the last block (two blocks) is shared by four (two)
+    wavefronts that split its conv positions and hand their partial fc1 sums to the group's leader (policy_ops.hip, "cooperative
+    blocks").  Against the numpy restatement of the reference's f32 forward, and against the same launch with every block on one
+    wavefront (OC_POLICY_COOP=0): equal to f32 rounding -- and NOT bit for bit, which shows the shared path ran; deterministic actions
+    agree wherever the two best log-probabilities are further apart than that rounding.  Ragged last block, actors and critics."""
+    from oracle.policy_oracle import log_softmax, reference_forward
+    rng = np.random.default_rng(W * 1000 + H * 10 + blocks)
+    wgs = 128                                                       # (a table of at least half as many tiles as CUs maps tile i to workgroup i)
+    n = wgs * blocks * 32 - 7                                       # every workgroup a stretch of `blocks` blocks, the very last one ragged
+    obs_np = (rng.random((n, W, H, 20)) < 0.15).astype(np.int8) * rng.integers(1, 21, size=(n, W, H, 20), dtype=np.int8)
+    actor, critic = random_net(W, H, 6, ACTOR_HEAD, 11), random_net(W, H, 1, CRITIC_HEAD, 12)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[actor], critics=[critic])
+    obs = torch.from_numpy(obs_np).cuda()
+    got = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("OC_POLICY_COOP", coop)
+        a = _run(nets, n, [(0, n, 0, TILE_ACT)], obs, rows_per_tile=blocks * 32, deterministic=True)
+        v = _run(nets, n, [(0, n, 1, 0)], obs, rows_per_tile=blocks * 32)["raw"].reshape(-1)[:n]
+        got[coop] = (a, v)
+    want_lp = log_softmax(reference_forward(actor, obs_np, ACTOR_HEAD))
+    want_v = reference_forward(critic, obs_np, CRITIC_HEAD).reshape(-1)
+    scale = max(1.0, float(np.abs(want_lp).max()), float(np.abs(want_v).max()))
+    for coop in ("1", "0"):
+        a, v = got[coop]
+        assert np.abs(a["logp"] - want_lp).max() < 4e-6 * scale and np.abs(v - want_v).max() < 4e-6 * scale, coop
+        top2 = np.sort(want_lp, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert np.array_equal(a["actions"][clear], want_lp.argmax(1)[clear]) and (a["actions"] >= 0).all()
+    (a1, v1), (a0, v0) = got["1"], got["0"]
+    assert np.abs(a1["logp"] - a0["logp"]).max() < 2e-6 * scale and np.abs(v1 - v0).max() < 2e-6 * scale
+    shared = blocks % 4 in (1, 2) and (W - 2) * (H - 2) >= 4
+    assert shared and not (np.array_equal(a1["logp"], a0["logp"]) and np.array_equal(v1, v0))
+    # only the shared blocks differ: the rows of a workgroup's first 4 k blocks are bit-identical
+    rows_wg = blocks * 32
+    full = np.concatenate([np.arange(w * rows_wg, w * rows_wg + (blocks - blocks % 4) * 32) for w in range(wgs)])
+    full = full[full < n]
+    assert np.array_equal(a1["logp"][full], a0["logp"][full]) and np.array_equal(v1[full], v0[full])
+
+
+@pytest.mark.gpu
+def test_multi_grid_launch_equals_per_grid_launches(monkeypatch):
     """oc_policy_forward_multi: three grids (6, 21 and 9 conv positions), actors and critics, ragged segments, ONE launch whose tile
-    table is balanced by block cost -- every output identical to the three per-grid launches with the same seeds and counter."""
+    table is balanced by block cost -- every output identical to the three per-grid launches with the same seeds and counter.
+    (Cooperative blocks off: which blocks are shared depends on how a plan cuts the rows, and a shared block sums its fc1 partials
+    in another order -- equal to f32 rounding, test_cooperative_blocks, not bit for bit across plans.)"""
+    monkeypatch.setenv("OC_POLICY_COOP", "0")
     from diverse_conventions_amd.fused_policy import MultiPolicyPlan, tile_slot
     rng = np.random.default_rng(31)
     grids, rows = [(5, 4), (9, 5), (5, 5)], [1000, 333, 2049]
@@ -583,7 +628,9 @@ def test_env_step_folded_into_the_policy_launch_equals_two_launches(layout, thre
     counters of the kitchen groups it touches, the wavefront that completes a group steps it inside the same launch) against the
     two-launch path (OC_POLICY_FOLD=0), same seeds: actions, log-probs, values, observations, rewards, dones and the engines' final
     state records must be identical -- time-major collection (fresh slots) and in-place stepping, pairing segments that do not
-    line up with the 32-kitchen fold groups, batches with one block per wavefront and with several, critics in the table."""
+    line up with the 32-kitchen fold groups, batches with one block per wavefront and with several, critics in the table.
+    (Cooperative blocks off for the two-launch side: the folded build has none, and a shared block rounds its fc1 sum differently.)"""
+    monkeypatch.setenv("OC_POLICY_COOP", "0")
     from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, TrajectoryBuffer
     params = layout_params[layout]
     W, H = params["width"], params["height"]

@@ -260,11 +260,13 @@ def test_the_group_binding_shown_in_integration_md_runs(layout_params):
 @pytest.mark.gpu
 @pytest.mark.parametrize("partition", [False, "one_launch"])
 @pytest.mark.parametrize("deterministic", [True, False])
-def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deterministic, layout_params):
+def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deterministic, layout_params, monkeypatch):
     """Policies in the loop over three layouts: per joint step three policy launches on the launch stream, or ONE policy launch
     over the three grids ("one_launch"), and ONE env launch.  Every engine's collected trajectory -- actions, log-probs, values,
     observations, rewards, dones -- must be exactly what its own FusedPairedRollout collects with the same seed, and the env
-    oracle driven by the recorded actions must reproduce the observations."""
+    oracle driven by the recorded actions must reproduce the observations.  (Cooperative blocks off: two plans over the same rows
+    share different blocks, and a shared block sums its fc1 partials in another order -- tests/test_fused_policy.py.)"""
+    monkeypatch.setenv("OC_POLICY_COOP", "0")
     from diverse_conventions_amd import (EngineGroup, FusedPairedRollout, GroupPairedRollout, OvercookedEngine, PackedNetworks,
                                          TrajectoryBuffer)
     names, threads, k, T = ["simple", "random0", "unident_s"], [48, 33, 20], 2, 14
