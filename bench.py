@@ -515,6 +515,45 @@ def main():
       except Exception as exc:                             # noqa: BLE001
         policy = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # Secondary figure, never `value`: BASELINE config 4 with the policies in the loop, one GPU's share on the 8-GPU node the config
+    # names -- asymmetric_advantages, 8184 kitchens, 16 conventions in 31 pairing segments, actors and one critic per segment on both
+    # sides in ONE policy launch per step + the env launch (what DESIGN.md 7's strong-scaling prediction is built from)
+    share = None
+    if policy is not None and "error" not in policy:
+      try:
+          from diverse_conventions_amd import FusedPairedRollout, PackedNetworks
+          sk, sthreads = 15, (65536 // 8) // 31
+          sG = 2 * sk + 1
+          sp = get_base_layout_params("asymmetric_advantages", 200)
+          sW, sH = sp["width"], sp["height"]
+          sP = (sW - 2) * (sH - 2)
+          g3 = torch.Generator().manual_seed(1)
+          r3 = lambda *sh: torch.randn(*sh, generator=g3) * 0.1
+          base3 = lambda: {"base.cnn.cnn.0.weight": r3(32, 20, 3, 3), "base.cnn.cnn.0.bias": r3(32), "base.cnn.cnn.3.weight": r3(64, 32 * sP),
+                           "base.cnn.cnn.3.bias": r3(64), "base.cnn.cnn.5.weight": r3(64, 64), "base.cnn.cnn.5.bias": r3(64)}
+          actors3 = [dict(base3(), **{"act.action_out.linear.weight": r3(6, 64), "act.action_out.linear.bias": r3(6)}) for _ in range(sk + 1)]
+          critics3 = [dict(base3(), **{"v_out.weight": r3(1, 64), "v_out.bias": r3(1)}) for _ in range(sG)]
+          nets3 = PackedNetworks.from_state_dicts((sW, sH, 20), "cuda", actors=actors3, critics=critics3)
+          eng3 = OvercookedEngine(sp, sthreads * sG, local)
+          ro3 = FusedPairedRollout(eng3, nets3, sthreads, sk, critic_nets=[[sk + 1 + g for g in range(sG)]] * 2)
+          ro3.step(SEC_WARMUP)
+          torch.cuda.synchronize()
+          t3 = time.perf_counter()
+          ro3.step(SEC_STEPS)
+          torch.cuda.synchronize()
+          share_us = (time.perf_counter() - t3) / SEC_STEPS * 1e6
+          share = {"what": f"BASELINE config 4, one GPU's share of 8: asymmetric_advantages, {eng3.num_kitchens} kitchens, {sk + 1} conventions in {sG} "
+                           f"pairing segments of {sthreads} kitchens, every actor and one critic per segment on both sides in ONE fused MFMA launch "
+                           "per step + the env launch, all steps enqueued by one call; random-weight reference-shape networks",
+                   "steps": SEC_STEPS, "kitchens": eng3.num_kitchens, "network_evaluations_per_step": 4 * eng3.num_kitchens, "us_per_step": share_us,
+                   "value": 2 * eng3.num_kitchens / share_us * 1e6, "unit": "agent-env steps/s",
+                   "checked": check_policy_in_loop(ro3, eng3, sp),
+                   "note": "stretches of 4 k + 1 blocks on the four-wavefront workgroups share their last block (cooperative blocks, DESIGN.md 9a): "
+                           "62.5 us per step without"}
+          eng3.close()
+      except Exception as exc:                             # noqa: BLE001
+        share = {"error": f"{type(exc).__name__}: {exc}"}
+
     build_info = eng.kernel_build_info
     if rank == 0:
         bytes_per_launch = algorithmic_bytes(S) * n
@@ -572,6 +611,8 @@ def main():
             out["fused_rollout"] = fused
         if policy is not None:
             out["policy_in_loop"] = policy
+        if share is not None:
+            out["config4_share_policy_in_loop"] = share
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, n)
         print(json.dumps(out), flush=True)
