@@ -52,12 +52,14 @@
         // that is not placed in the shadow of an MFMA costs its full latency.  While the 32 fc1 MFMAs of position
         // p run, the VALU turns the conv accumulators of position p+1 into fc1 operands (needed one iteration
         // later, so nothing waits for them), and the LDS reads for position p+2 are in flight.
-        // (a cooperative block: this wavefront's positions are p_first, p_first + p_step, ...; otherwise all of them)
-        const int p_first = cp ? member : 0, p_step = cp ? gsz : 1;
+        // (a cooperative block: this wavefront's positions are [p_first, p_end), the leader's run shorter by about the dense tail it
+        // runs alone afterwards -- coop_lead positions, see the kernel; otherwise all of them)
+        const int coop_rest = P - coop_lead, coop_each = cp ? coop_rest / (gsz - 1) : 0, coop_more = cp ? coop_rest - coop_each * (gsz - 1) : 0;
+        const int p_first = !cp ? 0 : member == 0 ? 0 : coop_lead + (member - 1) * coop_each + min(member - 1, coop_more);
+        const int p_end = !cp ? P : member == 0 ? coop_lead : p_first + coop_each + (member - 1 < coop_more ? 1 : 0);
         int pi = 0, xq = 0, yq = 0;                                   // position whose B operands `bfr` holds
-        auto advance1 = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
-        auto advance = [&]() { for (int i = 0; i < p_step; ++i) advance1(); };
-        for (int i = 0; i < p_first; ++i) advance1();
+        auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
+        for (int i = 0; i < p_first; ++i) advance();
         v4i bfr[6];
         read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
         v16i acc[NDIG];
@@ -143,7 +145,7 @@
             }
             if (!kLast) {
                 __builtin_amdgcn_sched_barrier(0);
-                load_w1(p + p_step);
+                load_w1(p + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) make_operand(xb, t);
@@ -154,7 +156,7 @@
         };
         {
             int p = p_first;
-            for (; p + p_step < P; p += p_step) position(p, std::false_type());
+            for (; p + 1 < p_end; ++p) position(p, std::false_type());
             position(p, std::true_type());
         }
         if (cp) {

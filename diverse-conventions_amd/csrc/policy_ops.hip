@@ -68,7 +68,8 @@ constexpr int kMaxOut = 8;
 #ifndef OC_POLICY_LATE_ROWS
 #define OC_POLICY_LATE_ROWS 1
 #endif
-constexpr bool kLateRows = OC_POLICY_LATE_ROWS != 0;   // see the network change in oc_policy_kernel
+constexpr bool kLateRows = OC_POLICY_LATE_ROWS != 0;
+constexpr int kCoopTailPositions = 3;  // cooperative blocks: the dense tail of a block in units of one conv position's time   // see the network change in oc_policy_kernel
 
 constexpr int kWaveTileBlocks = 12;    // segments shorter than this (in 32-row blocks, on average) run as wave tiles (oc_policy_plan_tiles_multi)
 constexpr int kMaxSlots = 8;           // observation tensors (grids) one launch can serve: tile flags carry the slot index
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     // wavefronts costs k + 1 rounds although the last round is one block on one SIMD (config 4's per-GPU share: 102 of 256 workgroups
     // have five blocks, and the launch is two blocks long for everybody).  The remainder -- one block per four wavefronts, or two on a
     // four-wavefront workgroup -- is therefore SHARED: the wavefronts of a group (one per SIMD) split the block's conv positions
-    // (member m takes m, m + g, ...), accumulate partial fc1 sums over their positions from the group leader's staged rows, and hand
+    // (a run of consecutive positions each), accumulate partial fc1 sums over their positions from the group leader's staged rows, and hand
     // them to the leader through their own (idle) staging areas; the leader adds them up and runs the dense tail alone.  Three
     // workgroup barriers per stretch, only here; every wavefront of the workgroup passes them.
     const int nb_stretch = last - first, rem = nb_stretch % nwaves;
@@ -754,6 +755,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const int gsz = (!kCoopBuild || !a.coop || rem == 0 || ((flags >> 8) & 0xff) || a.lds_wave_bytes < 8192) ? 0
                     : nwaves != 4 ? 0 : rem == 1 ? 4 : rem == 2 ? 2 : 0;
     const bool coop = gsz > 0 && P >= gsz;
+    // the leader also runs fc2, head and the epilogue -- about three positions' worth of time -- while the others are already idle:
+    // its run of positions is shorter by that much (L + 3 = (P - L) / (g - 1)), one position at least
+    const int coop_lead = coop ? min(max((P - kCoopTailPositions * (gsz - 1)) / gsz, 1), P - (gsz - 1)) : 0;
     const int last_full = coop ? last - rem : last;                   // blocks [first, last_full): one wavefront each
     const int grp = coop ? wave / gsz : 0, member = coop ? wave - grp * gsz : 0;
     const bool in_coop = coop && grp < rem, leader = in_coop && member == 0;
