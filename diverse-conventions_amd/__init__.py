@@ -15,10 +15,10 @@ from .policy import StackedActors, StackedCritics
 from .rollout import FusedPairedRollout, PairedRollout
 from .fused_policy import FusedVectorAgent, PackedNetworks, PolicyPlan
 from .mixed_play import MixedPlayRollout, MixedPlaySchedule
-from .sharding import KitchenShard, Segment, TrajectoryExchange, local_segments, pairing_segments
+from .sharding import KitchenShard, Segment, TrajectoryExchange, aligned_threads, local_segments, pairing_segments
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "EngineGroup", "GroupPairedRollout", "OvercookedMadrona",
-    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "StackedActors", "StackedCritics", "PairedRollout", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments",
+    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "StackedActors", "StackedCritics", "PairedRollout", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments", "aligned_threads",
 ]

@@ -60,6 +60,16 @@ def pairing_segments(threads: int, n_conventions: int) -> List[Segment]:
     return segs
 
 
+def aligned_threads(kitchens: int, n_conventions: int, multiple: int = 32) -> int:
+    """Kitchens per pairing segment for a budget of `kitchens` on one GPU: the largest multiple of 32 (the fused policy kernel's
+    block of rows) that fits the 2k+1 segments.  A segment of 264 kitchens is 8.25 blocks for each of its networks -- the ragged ninth
+    costs a whole block and pushes a workgroup into one more round; 256 are exactly 8.  Measured with actors and critics in the loop
+    (tools/exp_aligned_segments.py): config 4's per-GPU share 51.0 us per step at 31 x 264 kitchens, 41.5 at 31 x 256 (+19 % agent-env
+    steps/s); config 5's per-layout share 30.0 us at 63 x 130, 24.6 at 63 x 128.  Segments shorter than `multiple` are left alone."""
+    per = int(kitchens) // (2 * int(n_conventions) + 1)
+    return per if per < multiple else per - per % multiple
+
+
 def local_segments(threads_total: int, n_conventions: int, world: int, rank: int) -> List[Segment]:
     """The same segment structure on every GPU at 1/world of the threads: each rank
     evaluates every convention pair locally with replicated policy weights."""

@@ -23,6 +23,12 @@ def test_shards_cover_everything_once():
         assert max(s.count for s in shards) - min(s.count for s in shards) <= 1
 
 
+def test_aligned_threads():
+    from diverse_conventions_amd import aligned_threads
+    assert aligned_threads(8192, 15) == 256 and aligned_threads(8192, 31) == 128 and aligned_threads(65536, 7) == 4352
+    assert aligned_threads(100, 7) == 6 and aligned_threads(31 * 32, 15) == 32 and aligned_threads(8192, 15, multiple=64) == 256
+
+
 def test_pairing_segments_match_reference_slicing():
     # reference: envs = threads*(2k+1); sp = [:threads]; xp0_i = [threads*(i+1) : threads*(i+2)];
     # xp1_i = [threads*(i+1+k) : threads*(i+2+k)]   (train/XD/xd_player.py:102-140)
