@@ -106,6 +106,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     const LdsView L = carve(lds, a);
     const int lane = lane_id >= 0 ? lane_id : static_cast<int>(threadIdx.x);
     const int S = KP_S(a);
+    // (the grid size lives in the implicit kernel arguments, a cache line of its own: asked for here, together with the explicit
+    // ones, instead of where the group loop first needs it -- a scalar-cache miss in the middle of a wavefront's front)
+    asm volatile("" ::"s"(n_blocks));
 
     // ---- software pipeline: registers hold the *next* group's state block and actions
     // Loads are unconditional (indices clamped into the arrays) so that they land directly in the
@@ -145,18 +148,22 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     };
     unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (KP_trace(a)) stamp[0] = __builtin_amdgcn_s_memrealtime();
-    // first group's loads go out before anything else so their latency overlaps the table setup
-    int group = block_id;
-    prefetch(min(group, KP_n_groups(a) - 1));
-
     // ---- tables -> LDS, once per wave: the host lays the table image out exactly as carve() does, so it
-    // is one flat 16-byte copy (all loads in flight together instead of one round trip per table)
+    // is one flat 16-byte copy (all loads in flight together instead of one round trip per table).  The table loads go out FIRST
+    // (L2 hits), the first group's state and actions (HBM) behind them: vmcnt retires in order, so the counted wait for the table
+    // does not wait for the state.  The loads are unconditional and "landed" through an empty asm: left to itself the compiler sinks
+    // each into the `if` of its LDS write -- load, vmcnt(0), write, load, vmcnt(0), write: two round trips, the first of them behind
+    // the state loads, in front of everything a wavefront does (seen in the code object of the specialised build).
+    int group = block_id;
     {
         const uint4 *img = reinterpret_cast<const uint4 *>(a.tabs);
         const int nq4 = lds_table_dwords(S, KP_n_pots(a), KP_n_counters(a)) / 4;
         uint4 tq[kTabQ];
 #pragma unroll
         for (int q = 0; q < kTabQ; ++q) tq[q] = img[min(lane + q * kWave, nq4 - 1)];
+        prefetch(min(group, KP_n_groups(a) - 1));                 // the first group's loads: in flight during the table setup
+#pragma unroll
+        for (int q = 0; q < kTabQ; ++q) asm volatile("" : "+v"(tq[q].x), "+v"(tq[q].y), "+v"(tq[q].z), "+v"(tq[q].w));
 #pragma unroll
         for (int q = 0; q < kTabQ; ++q)
             if (lane + q * kWave < nq4) reinterpret_cast<uint4 *>(lds)[lane + q * kWave] = tq[q];
