@@ -106,9 +106,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     const LdsView L = carve(lds, a);
     const int lane = lane_id >= 0 ? lane_id : static_cast<int>(threadIdx.x);
     const int S = KP_S(a);
-    // (the grid size lives in the implicit kernel arguments, a cache line of its own: asked for here, together with the explicit
-    // ones, instead of where the group loop first needs it -- a scalar-cache miss in the middle of a wavefront's front)
-    asm volatile("" ::"s"(n_blocks));
 
     // ---- software pipeline: registers hold the *next* group's state block and actions
     // Loads are unconditional (indices clamped into the arrays) so that they land directly in the
