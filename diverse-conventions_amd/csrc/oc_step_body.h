@@ -201,7 +201,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
             }
         int raw0 = pa0, raw1 = pa1;
-        prefetch(min(group + n_blocks, KP_n_groups(a) - 1));     // last iteration: harmless re-read
+        if (group + n_blocks < KP_n_groups(a)) prefetch(group + n_blocks);   // (wave-uniform; the last group: nothing to fetch)
         wave_sync();
         if (KP_trace(a) && stamp[6] == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
         const int64_t plane_base = k0 * S * kChannels;   // byte offset of this group's kitchens in a viewer plane
