@@ -1279,6 +1279,16 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
 
 extern "C" {
 
+// While one of these lives, the engine's steps into fresh (time-major) slots store their planes plainly: the launch that follows
+// reads them (oc_internal_planes_read_next).
+struct PlanesReadNext {
+    oc_engine *e;
+    explicit PlanesReadNext(oc_engine *e_) : e(e_) { oc_internal_planes_read_next(e, 1); }
+    ~PlanesReadNext() { oc_internal_planes_read_next(e, 0); }
+    PlanesReadNext(const PlanesReadNext &) = delete;
+    PlanesReadNext &operator=(const PlanesReadNext &) = delete;
+};
+
 // the env step folded into the launch (oc_policy_rollout): the engine's step arguments for this step and the fold groups' counters
 struct FoldParams {
     const oc_dev::StepArgs *args;       // device template (oc_internal_fold_workspace)
@@ -1409,6 +1419,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
             fold = true;
         }
     }
+    const PlanesReadNext hint(e);                                     // (every step's planes are the next policy launch's input)
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
         int8_t *obs_t = d_obs + k * slot, *obs_next = in_place ? d_obs : d_obs + (t + 1) * slot;
@@ -1448,6 +1459,7 @@ int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const vo
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout_mixed: cannot make device %d current", oc_device_id(e));
     // every step's rows sorted by who plays them, for all steps at once: list 2t + side holds row ids side * N + kitchen
     if (int rc = oc_partition_rows(d_choice, 2 * T, n, 2, d_index_ws, d_count_ws, stream)) return rc;
+    const PlanesReadNext hint(e);
     for (int64_t t = 0; t < T; ++t) {
         int32_t *act_t = d_actions + t * rows;
         // (step t reads slot t and the env step writes slot t + 1: the 12 bytes a ragged row's last piece may over-read lie inside the buffer)
