@@ -1283,8 +1283,11 @@ extern "C" {
 // reads them (oc_internal_planes_read_next).
 struct PlanesReadNext {
     oc_engine *e;
-    explicit PlanesReadNext(oc_engine *e_) : e(e_) { oc_internal_planes_read_next(e, 1); }
-    ~PlanesReadNext() { oc_internal_planes_read_next(e, 0); }
+    oc_group *g;
+    explicit PlanesReadNext(oc_engine *e_) : e(e_), g(nullptr) { oc_internal_planes_read_next(e, 1); }
+    explicit PlanesReadNext(oc_group *g_) : e(nullptr), g(g_) { set(1); }
+    ~PlanesReadNext() { if (g) set(0); else oc_internal_planes_read_next(e, 0); }
+    void set(int on) { for (int i = 0; oc_internal_group_engine(g, i); ++i) oc_internal_planes_read_next(oc_internal_group_engine(g, i), on); }
     PlanesReadNext(const PlanesReadNext &) = delete;
     PlanesReadNext &operator=(const PlanesReadNext &) = delete;
 };
@@ -1563,6 +1566,7 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
     const OcDeviceScope on_device(oc_device_id(eng[0]));
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: cannot make device %d current", oc_device_id(eng[0]));
     hipStream_t main_stream = static_cast<hipStream_t>(stream);
+    const PlanesReadNext hint(g);                                     // (every step's planes are the next policy launches' input)
     bool side = policy_streams != nullptr;
     for (int i = 0; i < n && side; ++i) side = policy_streams[i] != nullptr && policy_streams[i] != stream;
     auto policy = [&](int i, int64_t t, hipStream_t st, int budget) {
@@ -1646,6 +1650,7 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
     std::vector<const void *> act(n);
     std::vector<int8_t *> obs_next(n);
     std::vector<int32_t *> rew(n), done(n);
+    const PlanesReadNext hint(g);
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
         for (int i = 0; i < n; ++i) {
