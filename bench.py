@@ -494,6 +494,18 @@ def main():
           else:
               os.environ["OC_POLICY_FOLD"] = fold_before
           step_us = min(step_modes.values())
+          # ... and what training does: the same two launches per step, every step's planes into their own time-major slot
+          # (TrajectoryBuffer; the fresh planes are stored plainly while the rollout runs -- the next launch reads them)
+          from diverse_conventions_amd import TrajectoryBuffer
+          ctraj = TrajectoryBuffer(eng2, 200)
+          ro.collect(ctraj)
+          torch.cuda.synchronize()
+          t1 = time.perf_counter()
+          for _ in range(3):
+              ro.collect(ctraj)
+          torch.cuda.synchronize()
+          step_modes["two_launches_time_major_slots"] = (time.perf_counter() - t1) / 600 * 1e6
+          del ctraj
           rows = 2 * eng2.num_kitchens
           cycles = rows / 32 * 32 * (P * (6 * nets.digits + 24) + 48 + 24)     # MFMA issue cycles (i8 conv digits + bf16 piece products), DESIGN 9a
           cus = torch.cuda.get_device_properties(local).multi_processor_count
