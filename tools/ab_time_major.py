@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch geometries for the time-major destination (every step's planes into their own slot, non-temporal stores):
-interleaved A/B like tools/ab_geometry.py.  Candidates kpw,passes,wpc[,fast flush]."""
+interleaved A/B like tools/ab_geometry.py.  Candidates kpw,passes,wpc[,fast flush[,fresh store mode]]."""
 import os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,10 @@ for cand in cands:
         os.environ["OC_FAST_FLUSH"] = str(cand[3])
     else:
         os.environ.pop("OC_FAST_FLUSH", None)
+    if len(cand) > 4:                                     # fifth field: store mode of fresh destinations (0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt)
+        os.environ["OC_STORE_MODE"] = f"2,{cand[4]}"
+    else:
+        os.environ.pop("OC_STORE_MODE", None)
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(*cand[:3])
     engines.append(e)
