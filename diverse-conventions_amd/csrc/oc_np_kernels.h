@@ -47,7 +47,9 @@ __device__ __forceinline__ int np_count(uint32_t o) { return static_cast<int>(((
 // ref:381-385 get_state_transition + the wrappers' done / reward / reset rule (envs/overcooked2_env.py:327-339,
 // pantheonrl_extension/vectorenv.py:369-370), one thread per kitchen.
 // (Staging the block's records through LDS for coalesced access was measured and is slower: 111 vs 109 us per step at 4 x 65 536
-// kitchens -- the index arithmetic of the copy loops and two barriers cost more than the scattered dword accesses, which L2 serves.)
+// kitchens -- the index arithmetic of the copy loops and two barriers cost more than the scattered dword accesses, which L2 serves.
+// Round 3 tried it once more per wavefront -- 64 kitchens' records as one flat 16-byte-per-lane copy at an odd LDS stride, no barrier:
+// 107.5-108.0 against 108.3-109.0 us, i.e. nothing: this kernel's time is not in its record accesses.)
 __global__ void np_step_kernel(const NpArgs a) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= a.n) return;
