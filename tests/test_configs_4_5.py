@@ -269,3 +269,50 @@ def test_config5_shape_rollout_gae_minibatch(layout_params):
         _check_policies(shim, trajs[i], lps[i], vas[i], kept[i][1], kept[i][2], kept[i][3], T2, kept[i][4])
     gro.close()
     grp.close(close_engines=True)
+
+
+def test_policy_rollout_into_fresh_slots_at_the_large_batch_geometry(layout_params):
+    """A policy rollout that COLLECTS (every step's planes into their own time-major slot) on a batch large enough for the
+    fresh-destination module (16 kitchens per group, eight wavefronts per CU): while the rollout runs the planes are stored plainly --
+    the next launch, the policy kernel, reads them (`_pl` entry points, oc_internal_planes_read_next) -- instead of streamed past the
+    caches.  3 x 64 sampled kitchens of the recorded trajectory replayed through the env oracle, across an episode boundary; the
+    recorded log-probabilities against the per-segment PyTorch evaluation on the sampled rows."""
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer
+    params = dict(layout_params["simple"], horizon=6)
+    k, threads, T = 2, 10240, 9                                       # 5 segments x 10 240 = 51 200 kitchens (>= 49 137: the fresh geometry)
+    G, n = 2 * k + 1, threads * (2 * k + 1)
+    actors, _ = _random_nets(5, 4, k + 1, 0, 77)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=actors)
+    eng = OvercookedEngine(params, n, 0)
+    assert "specialised" in eng.kernel_build_info
+    ro = FusedPairedRollout(eng, nets, threads, k, seed=3)
+    ro.step(2)                                                        # (in place first: the collection then starts from a used engine)
+    firsts = [0, n // 2 - 32, n - 64]
+    starts = [eng.get_state(f, 64) for f in firsts]
+    traj = TrajectoryBuffer(eng, T)
+    logp = torch.zeros((T, 2, n), device="cuda")
+    ro.collect(traj, logp=logp)
+    torch.cuda.synchronize()
+    for f, (tiles, players, ts) in zip(firsts, starts):
+        ora = oracle.OracleVecEnv(params, 64)
+        ora.set_state(tiles, players, ts)
+        sl = slice(f, f + 64)
+        assert np.array_equal(traj.obs[0][:, sl].cpu().numpy(), ora.encode())
+        for t in range(T):
+            oobs, orew, odone = ora.step(np.ascontiguousarray(traj.actions[t][:, sl].cpu().numpy()))
+            assert np.array_equal(traj.obs[t + 1][:, sl].cpu().numpy(), oobs), (f, t)
+            assert np.array_equal(traj.reward[t][:, sl].cpu().numpy(), orew) and np.array_equal(traj.done[t][sl].cpu().numpy(), odone), (f, t)
+    assert int(traj.done.sum()) > 0                                   # the horizon was crossed inside the collection
+    # the log-probabilities recorded for the sampled kitchens' actions: the segment's actor on the recorded observations
+    from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+    sa = StackedActors(actors, (5, 4, 20), "cuda")
+    for p, side in enumerate(("ego", "partner")):
+        pol = segment_policy_indices(ro.segments, side)
+        for f in firsts:
+            g = f // threads
+            assert (f + 63) // threads == g
+            obs = traj.obs[:T, p, f:f + 64].reshape(1, T * 64, 5, 4, 20)
+            lp = sa.log_probs(obs, selected=sa.select(torch.tensor([pol[g]]))).view(T, 64, 6)
+            got = lp.gather(-1, traj.actions[:, p, f:f + 64].long().unsqueeze(-1)).squeeze(-1)
+            assert (got - logp[:, p, f:f + 64]).abs().max() < 8e-6
+    eng.close()
