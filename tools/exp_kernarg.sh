@@ -1,3 +1,7 @@
+# Where do kernel arguments live?  HIP_FORCE_DEV_KERNARG=0 (host memory) against 1 (device memory: this ROCm's default): bench.py and the
+# policy kernel's phase trace under both.  Result (second session of round 3): device memory already is the default here -- host-side
+# arguments cost the env launch 1.8 us and the policy prologue 3 us; nothing to gain from the variable.
+#   gpurun -- 'bash tools/exp_kernarg.sh'   -> gpurun_out/r03b_kernarg_{0,1}.log, r03b_trace_kernarg_{0,1}.log
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
