@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: agent-env steps/s of the fused step+encode path (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]            # N=1
+    python bench.py [--gpus N --steps K --warmup W]            # N=1; N>1 starts its own ranks as a child torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -127,33 +127,50 @@ def check_distinct_devices(idents, allow_shared=False):
 def exchange_leg(world, rank, local, backend, gen, c4_step_s):
     """The one real collective of a sharded run (consumer: the reference's XP / MP losses read whole buffers,
     train/XD/xd.py:311-397): every rank's compact trajectory of BASELINE config 4 -- asymmetric_advantages, 65 536 / world
-    kitchens, T = 200 steps of [state records | actions | reward | done] -- through TrajectoryExchange.gather_trajectory (ONE
-    all_gather_into_tensor) and the receive side, featurize_all (one oc_encode_trajectory launch per peer).  Timed with events on
-    the current stream after a full warm-up exchange; checked: every peer's re-featurised block against checksums its owner took
-    of the observations its own engine wrote during the rollout.  Returns the dict for the JSON line (same on every rank)."""
+    kitchens, T = 200 steps of [state records | actions | reward | done], ONE flat int32 wire buffer that the rollout's own launches
+    fill in place (TrajectoryBuffer(store_states=True): the step kernel writes the records, no export pass) -- handed AS IT IS to
+    TrajectoryExchange.gather_buffer (ONE all_gather_into_tensor, no concatenation pass) and the receive side, featurize_all (one
+    oc_encode_trajectory launch per peer).  Timed with events on the current stream after a full warm-up exchange; checked: every
+    peer's re-featurised block against checksums its owner took of the observations its own engine wrote during the rollout.
+    Returns the dict for the JSON line (same on every rank)."""
     import torch
     import torch.distributed as dist
-    from diverse_conventions_amd import OvercookedEngine, TrajectoryExchange, get_base_layout_params
+    from diverse_conventions_amd import OvercookedEngine, TrajectoryBuffer, TrajectoryExchange, get_base_layout_params
     total = 65536
     T = int(os.environ.get("OC_BENCH_EXCHANGE_T", "200"))            # test hook: a shorter trajectory
     n = total // world
     params = get_base_layout_params("asymmetric_advantages", 200)
     eng = OvercookedEngine(params, n, local)
     dev = eng.device
-    r4 = eng.record_bytes // 4
-    rec = torch.empty((T, n, r4), dtype=torch.int32, device=dev)
-    rew = torch.empty((T, 2, n), dtype=torch.int32, device=dev)
-    done = torch.empty((T, n), dtype=torch.int32, device=dev)
-    acts = torch.randint(0, 6, (T, 2, n), generator=gen, device=dev, dtype=torch.int32)
     eng.stagger()                                                    # episode phases spread out: resets all along the trajectory
-    probe_t = sorted({0, T // 2, T - 1})
+    traj = TrajectoryBuffer(eng, T, store_states=True, obs_slots=1)  # compact fields = views of one wire buffer; one obs slot, in place
+    acts = torch.randint(0, 6, (T, 2, n), generator=gen, device=dev, dtype=torch.int32)
+    probe_t = sorted({0, T // 2, T})
     own_sums = {}
-    for t in range(T):                                               # the rollout that fills the shard (not timed here)
-        eng.export_states(out=rec[t])
+    traj.start()
+    for t in range(T):                                               # the rollout that fills the shard (not timed here): ONE launch per step
         if t in probe_t:
-            own_sums[t] = _checksum(eng.observe())                   # what this rank's engine says slot t looks like
-        eng.step(acts[t], reward=rew[t], done=done[t])
+            own_sums[t] = _checksum(traj.obs[0])                     # what this rank's engine says slot t looks like
+        traj.step(acts[t])
+    own_sums[T] = _checksum(traj.obs[0])
     torch.cuda.synchronize()
+    # what the record destination saves: the same T steps with an export_states launch behind each step (round 3's way)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    scratch = torch.empty_like(traj.records[0])
+    e0.record()
+    for t in range(T):
+        eng.step(acts[t])
+        eng.export_states(out=scratch)
+    e1.record()
+    torch.cuda.synchronize()
+    two_pass_us = e0.elapsed_time(e1) * 1e3 / T
+    e0.record()
+    for t in range(T):
+        eng.step(acts[t], records=scratch)
+    e1.record()
+    torch.cuda.synchronize()
+    one_pass_us = e0.elapsed_time(e1) * 1e3 / T
+    del scratch
     # control plane: who is where (fails loudly when two ranks share a device and that was not asked for)
     ident = {"rank": rank, "device_index": local, "name": torch.cuda.get_device_name(local)}
     try:
@@ -172,15 +189,16 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
     else:
         idents, sums_all = [ident], [own_sums]
     check_distinct_devices(idents, allow_shared="OC_BENCH_DEVICE" in os.environ)
-    # gloo (test hook OC_BENCH_BACKEND) moves host buffers; RCCL moves the device buffers as they are
+    # gloo (test hook OC_BENCH_BACKEND) moves host buffers; RCCL moves the device buffer as it is
     on_host = backend != "nccl"
     ex = TrajectoryExchange(always_collective=True)
-    fields = (rec, acts, rew[:, 0].contiguous(), done)
+    send = traj
     if on_host:
-        fields = tuple(f.cpu() for f in fields)
-    words = sum(f.numel() for f in fields)
-    sent_bytes = 4 * (words + (-words) % 4)
-    out = torch.empty((T, 2, world * n, eng.width, eng.height, 20), dtype=torch.int8, device=dev)
+        from types import SimpleNamespace
+        send = SimpleNamespace(T=traj.T, P=traj.P, engine=eng, wire=traj.wire.cpu())
+    sent_bytes = 4 * traj.wire.numel()
+    recv = torch.empty(world * traj.wire.numel(), dtype=torch.int32, device="cpu" if on_host else dev)     # persistent receive buffer
+    out = torch.empty((T + 1, 2, world * n, eng.width, eng.height, 20), dtype=torch.int8, device=dev)
 
     def once():
         e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
@@ -189,7 +207,7 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
-        got = ex.gather_trajectory(*fields)
+        got = ex.gather_buffer(send, out=recv)
         e1.record()
         if on_host:                                                   # events see nothing of a gloo transfer of host buffers
             wall = time.perf_counter() - t0
@@ -208,9 +226,22 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
     got = runs[-1][0]
     gather_ms = sum(r[1] for r in runs) / reps
     feat_ms = sum(r[2] for r in runs) / reps
+    # what round 3's path paid on top: one concatenation of the four loose fields into a send buffer (read + write of the shard)
+    cat_ms = None
+    if not on_host:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        loose = (traj.records.reshape(-1), traj.actions.reshape(-1), traj.reward.reshape(-1), traj.done.reshape(-1))
+        torch.cat(loose)
+        e0.record()
+        torch.cat(loose)
+        e1.record()
+        torch.cuda.synchronize()
+        cat_ms = e0.elapsed_time(e1)
     # check: own fields come back at index `rank`, and every peer's block of the re-featurised tensor has the checksum its owner
     # computed from its own engine's observation of that slot
-    ok = all(torch.equal(got[k][rank], f) for k, f in zip(("records", "actions", "reward", "done"), fields))
+    own = {"records": send.wire[:traj.records.numel()].view(traj.records.shape)}
+    ok = bool(torch.equal(got["records"][rank], own["records"]))
+    ok = ok and all(torch.equal(got[k][rank].to(dev), getattr(traj, k)) for k in ("actions", "reward", "done"))
     for r in range(world):
         for t in probe_t:
             ok = ok and _checksum(out[t, :, r * n:(r + 1) * n]) == tuple(sums_all[r][t])
@@ -219,7 +250,7 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     gather_ms, feat_ms, bad = (float(x) for x in stats)
     eng.close()
-    del out
+    del out, recv
     try:
         rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:                                                 # noqa: BLE001
@@ -227,16 +258,18 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
     update_s = T * c4_step_s + gather_ms / 1e3 + feat_ms / 1e3
     return {
         "what": f"BASELINE config 4's per-update exchange: asymmetric_advantages, {total} kitchens in total = {n} per GPU, T = {T} compact "
-                "steps (state records + actions + reward + done, 4S+16+16 B per kitchen-step) through ONE all_gather_into_tensor, then "
-                "every peer's shard re-featurised on the receiver (oc_encode_trajectory, one launch per peer)",
+                "steps (T+1 state record slots + actions + reward + done: one flat wire buffer the step launches fill in place) through ONE "
+                "all_gather_into_tensor as it is, then every peer's shard re-featurised on the receiver (oc_encode_trajectory, one launch per peer)",
         "steps": T, "kitchens_per_gpu": n, "collectives_per_update": 1, "reps": reps,
         "MB_sent_per_gpu": sent_bytes / 1e6, "MB_received_per_gpu": sent_bytes * (world - 1) / 1e6,
         "exchange_ms": gather_ms, "GBps_per_gpu_sent": sent_bytes * max(world - 1, 1) / gather_ms / 1e6,
+        "concatenation_ms_saved": cat_ms,
+        "record_step_us": {"one_launch_with_record_destination": one_pass_us, "step_plus_export_states": two_pass_us},
         "model_ms_direct_all_gather": sent_bytes / XGMI_LINK_GBS / 1e6,
         "model_note": f"direct all-gather: a GPU pushes its shard to each peer over that peer's own xGMI link ({XGMI_LINK_GBS:.0f} GB/s each, "
                       "all links at once), so the model time is shard bytes / one link whatever the world size; a single ring would take (world-1) x that",
-        "refeaturize_ms": feat_ms, "refeaturize_GB_written": T * 2 * world * n * eng.size * 20 / 1e9,
-        "refeaturize_GBps": T * 2 * world * n * eng.size * 20 / feat_ms / 1e6,
+        "refeaturize_ms": feat_ms, "refeaturize_GB_written": (T + 1) * 2 * world * n * eng.size * 20 / 1e9,
+        "refeaturize_GBps": (T + 1) * 2 * world * n * eng.size * 20 / feat_ms / 1e6,
         "checked": bad == 0.0,
         "rccl": {"backend": backend if dist.is_initialized() else None, "world": world, "version": rccl_version,
                  "transport": "device buffers" if not on_host else "host buffers (gloo test hook)", "devices": idents},
@@ -244,6 +277,34 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
         "update_amortised_note": f"config 4 over one PPO update: {T} env steps at the config4_split step time + one exchange + the "
                                  "re-featurisation, whole job",
     }
+
+
+def self_launch(n_ranks):
+    """Start the N ranks of `bench.py --gpus N` the way the driver does -- python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments> -- as a child process, relay its
+    output and return its exit code.  The caller (this process) never touches the GPU: on this pool a process that has initialised
+    the GPU must not start other GPU programs, and the parent has no use for a device anyway."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, OC_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)      # stderr goes straight through
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith("{"):
+            lines += 1
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py launcher: expected ONE JSON line from rank 0, saw {lines}", file=sys.stderr)
+        return 1
+    return rc
 
 
 def check_policy_in_loop(ro, eng, params, T=24, blocks=4, per_block=64):
@@ -292,6 +353,12 @@ def main():
                     help="headline measurement only (profiling runs: every launch of the step kernel is then the headline workload's)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process becomes the launcher.  It has made
+    # no GPU call (torch is not even imported yet) and makes none: the N ranks are CHILD processes of torch.distributed.run, whose
+    # one JSON line and exit code are relayed.  Under an external launcher (WORLD_SIZE set) nothing of this runs.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
@@ -300,7 +367,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    launcher = os.environ.get("OC_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none")
     # test hooks (a 1-GPU box cannot host two NCCL ranks): OC_BENCH_DEVICE pins every rank to one device,
     # OC_BENCH_BACKEND=gloo swaps the control-plane backend; the driver's multi-GPU runs use neither
     if "OC_BENCH_DEVICE" in os.environ:
@@ -477,23 +545,17 @@ def main():
           pe1.record()
           torch.cuda.synchronize()
           pol_us = pe0.elapsed_time(pe1) * 1e3 / psteps
-          # the whole step, both ways: two launches (policy, env) and ONE (the env step folded into the policy launch: every
-          # actor block bumps the arrival counters of the kitchen groups it touches, the wavefront that completes a group steps it)
+          # the whole step: a policy launch and an env launch, every launch of every step enqueued from C by one call (the env step
+          # folded INTO the policy launch was built and measured in round 3 -- 116 against 60 us per step -- and lives behind the
+          # diagnostics build now: DESIGN.md 9b, tools/exp_fold_ab.py)
           step_modes = {}
-          fold_before = os.environ.get("OC_POLICY_FOLD")
-          for mode, flag in (("two_launches", "0"), ("one_launch", "1")):
-              os.environ["OC_POLICY_FOLD"] = flag
-              ro.step(SEC_WARMUP)
-              torch.cuda.synchronize()
-              t1 = time.perf_counter()
-              ro.step(psteps)                              # every launch of every step enqueued from C by one call
-              torch.cuda.synchronize()
-              step_modes[mode] = (time.perf_counter() - t1) / psteps * 1e6
-          if fold_before is None:
-              os.environ.pop("OC_POLICY_FOLD", None)
-          else:
-              os.environ["OC_POLICY_FOLD"] = fold_before
-          step_us = min(step_modes.values())
+          ro.step(SEC_WARMUP)
+          torch.cuda.synchronize()
+          t1 = time.perf_counter()
+          ro.step(psteps)
+          torch.cuda.synchronize()
+          step_modes["two_launches"] = (time.perf_counter() - t1) / psteps * 1e6
+          step_us = step_modes["two_launches"]
           # ... and what training does: the same two launches per step, every step's planes into their own time-major slot
           # (TrajectoryBuffer; the fresh planes are stored plainly while the rollout runs -- the next launch reads them)
           from diverse_conventions_amd import TrajectoryBuffer
@@ -566,6 +628,101 @@ def main():
       except Exception as exc:                             # noqa: BLE001
         share = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # Secondary figure, never `value`: BASELINE config 2 -- cramped_room, 4096 kitchens, step + encode kernel only: per launch
+    # (launch-bound: 4 MB per step) and as the K-steps-per-launch rollout
+    config2 = None
+    if world == 1 and not args.no_secondary:
+        c2_n = 4096
+        c2_params = get_base_layout_params("cramped_room", 200)
+        eng_c2 = OvercookedEngine(c2_params, c2_n, local)
+        act_c2 = torch.randint(0, 6, (t_act, 2, c2_n), generator=gen, device="cuda", dtype=torch.int32)
+        eng_c2.rollout(act_c2, SEC_WARMUP)
+        c2_us = eng_c2.rollout_timed(act_c2, SEC_STEPS) * 1e3 / SEC_STEPS
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eng_c2.rollout_fused(SEC_WARMUP, actions=act_c2)
+        ev0.record()
+        eng_c2.rollout_fused(SEC_STEPS, actions=act_c2)
+        ev1.record()
+        torch.cuda.synchronize()
+        c2_fused_us = ev0.elapsed_time(ev1) * 1e3 / SEC_STEPS
+        c2_bytes = algorithmic_bytes(20) * c2_n
+        config2 = {"what": "BASELINE config 2: cramped_room, 4096 parallel kitchens, random-action rollout, step + encode kernel only",
+                   "steps": SEC_STEPS, "kitchens": c2_n, "us_per_launch": c2_us, "value": 2 * c2_n / c2_us * 1e6, "unit": "agent-env steps/s",
+                   "bytes_per_launch": c2_bytes, "achieved_GBps": c2_bytes / c2_us / 1e3, "frac_of_8TBps": c2_bytes / c2_us / 1e3 / HBM_PEAK_GBS,
+                   "kernel_build": eng_c2.kernel_build_info,
+                   "fused_rollout_us_per_step": c2_fused_us, "fused_rollout_value": 2 * c2_n / c2_fused_us * 1e6,
+                   "note": "one launch per step is launch-bound at this size (a wavefront's own critical path is ~3.4 us, DESIGN.md 5); the "
+                           "K-steps-per-launch rollout has no launch boundary per step"}
+        eng_c2.close()
+
+    # Secondary figure, never `value`: the mixed-play collection: 329 x 199 = 65 471 kitchens, two episodes of
+    # L = 200 steps, per step ONE gathered policy launch (every row evaluated once, by the network the coin gave it) + the env
+    # launch, all 2L steps enqueued by one call; checked: sampled kitchens replayed through the CPU oracle with the recorded actions
+    mixed = None
+    if policy is not None and "error" not in policy:
+      try:
+          import numpy as np
+          from diverse_conventions_amd import MixedPlayRollout, PackedNetworks
+          from oracle import oracle
+          mL, mreps = 200, 329
+          mn = mreps * (mL - 1)
+          mparams = get_base_layout_params("cramped_room", mL)
+          mW, mH = mparams["width"], mparams["height"]
+          mP = (mW - 2) * (mH - 2)
+          g4 = torch.Generator().manual_seed(2)
+          r4 = lambda *sh: torch.randn(*sh, generator=g4) * 0.1
+          mbase = lambda: {"base.cnn.cnn.0.weight": r4(32, 20, 3, 3), "base.cnn.cnn.0.bias": r4(32), "base.cnn.cnn.3.weight": r4(64, 32 * mP),
+                           "base.cnn.cnn.3.bias": r4(64), "base.cnn.cnn.5.weight": r4(64, 64), "base.cnn.cnn.5.bias": r4(64)}
+          mactors = [dict(mbase(), **{"act.action_out.linear.weight": r4(6, 64), "act.action_out.linear.bias": r4(6)}) for _ in range(2)]
+          mcritics = [dict(mbase(), **{"v_out.weight": r4(1, 64), "v_out.bias": r4(1)}) for _ in range(2)]
+          mnets = PackedNetworks.from_state_dicts((mW, mH, 20), "cuda", actors=mactors, critics=mcritics)
+          meng = OvercookedEngine(mparams, mn, local)
+          mro = MixedPlayRollout(meng, mnets, mL, main=(0, 2), partner=(1, 3), seed=3)
+          mro.collect()
+          torch.cuda.synchronize()
+          t5 = time.perf_counter()
+          mro.collect()
+          torch.cuda.synchronize()
+          m_s = time.perf_counter() - t5
+          # outside the timed region: 3 x 48 kitchens (first, middle, last roles of the staircase) through the oracle
+          m_ok, per = True, 48
+          for f in (0, (mn - per) // 2, mn - per):
+              ora = oracle.OracleVecEnv(mparams, per)
+              sl = slice(f, f + per)
+              m_ok = m_ok and np.array_equal(mro.traj.obs[0][:, sl].cpu().numpy(), ora.encode())
+              a_all = mro.traj.actions[:, :, sl].cpu().numpy()
+              for t in range(2 * mL):
+                  oobs, orew, odone = ora.step(np.ascontiguousarray(a_all[t]))
+                  if t % 25 == 0 or t in (mL - 1, mL, 2 * mL - 1):
+                      m_ok = m_ok and np.array_equal(mro.traj.obs[t + 1][:, sl].cpu().numpy(), oobs)
+                  m_ok = m_ok and np.array_equal(mro.traj.reward[t][:, sl].cpu().numpy(), orew) and np.array_equal(mro.traj.done[t][sl].cpu().numpy(), odone)
+          mixed = {"what": f"mixed-play collection: cramped_room, {mn} kitchens = {mreps} x {mL - 1} roles of the staircase, two episodes of L = {mL} "
+                           "steps, per step one gathered policy launch (2 actors + 2 critics, every row evaluated once) + the env launch, one call",
+                   "steps": 2 * mL, "kitchens": mn, "collect_ms": m_s * 1e3, "us_per_step": m_s / (2 * mL) * 1e6,
+                   "value": 2 * mn * 2 * mL / m_s, "unit": "agent-env steps/s", "checked": bool(m_ok),
+                   "checked_note": "3 x 48 kitchens (first / middle / last staircase roles) replayed through the CPU oracle with the recorded "
+                                   "actions: rewards and dones at every step, observations at 20 steps incl. both episode ends"}
+          meng.close()
+          del mro
+      except Exception as exc:                             # noqa: BLE001
+        mixed = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # At N = 1 the exchange leg still runs, as a one-rank RCCL call on device buffers (a one-rank all-gather is a copy through RCCL's
+    # channels: it says nothing about xGMI, but the collective, the wire buffer and the receive side are the ones an 8-GPU run uses)
+    if exchange is None and world == 1 and not args.no_secondary and not use_dist and torch.cuda.is_available():
+      try:
+          import socket
+          with socket.socket() as sock:
+              sock.bind(("127.0.0.1", 0))
+              port = sock.getsockname()[1]
+          dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", local))
+          try:
+              exchange = exchange_leg(1, 0, local, "nccl", gen, c4_wall / c4_steps)
+          finally:
+              dist.destroy_process_group()
+      except Exception as exc:                             # noqa: BLE001
+        exchange = {"error": f"{type(exc).__name__}: {exc}"}
+
     build_info = eng.kernel_build_info
     if rank == 0:
         bytes_per_launch = algorithmic_bytes(S) * n
@@ -594,7 +751,7 @@ def main():
             "metric": "agent-env steps/sec at 64k parallel kitchens, 1/2/4/8 MI355X",
             "value": 2 * n * world * args.steps / wall,
             "unit": "agent-env steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "launcher": launcher,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -621,6 +778,10 @@ def main():
             if c3 is not None:
                 out["config3_one_launch"] = c3
             out["fused_rollout"] = fused
+        if config2 is not None:
+            out["config2"] = config2
+        if mixed is not None:
+            out["mixed_play"] = mixed
         if policy is not None:
             out["policy_in_loop"] = policy
         if share is not None:

@@ -430,6 +430,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 flush_passes(p0);
                 wave_sync();
             }
+            // ---- trajectory recording: the post-step records to the caller's slot, in the launch that computed them (the next
+            // launch's input stays the engine's own block, written below); like the planes they go to a destination nobody
+            // re-reads soon, hence the planes' store mode
+            if (STEP && a.rec_out) {
+                uint4 *rdst = a.rec_out + (FUSED ? step * a.rec_step_stride : 0) + k0 * KP_recq(a);
+#pragma unroll
+                for (int q = 0; q < QN; ++q)
+                    if (lane + q * kWave < nq) {
+                        const uint32_t *sp = L.state + loff[q];
+                        store16<SM>(reinterpret_cast<int8_t *>(rdst + lane + q * kWave), make_uint4(sp[0], sp[1], sp[2], sp[3]));
+                    }
+            }
 
         }   // step loop
 

@@ -181,6 +181,10 @@ struct StepArgs {
     int32_t batch_groups;       // groups per batch item = ceil(n_kitchens / kpw)
     int64_t state_batch_stride; // uint4 between consecutive items' record blocks
     int64_t obs_batch_stride;   // bytes between consecutive items' viewer-0 planes
+    // trajectory recording (STEP kernels): the post-step state records also go to rec_out (same [N][recq] layout as `state`, 16-byte
+    // aligned), step t of a FUSED rollout to rec_out + t * rec_step_stride; NULL = not recorded
+    uint4 *rec_out;
+    int64_t rec_step_stride;    // uint4 between consecutive steps' record blocks (FUSED kernels only)
     int32_t ablate;             // timing diagnostics only (env OC_ABLATE at oc_create); 0 in production
     unsigned long long *trace;  // timing diagnostics only: [wave][8] s_memrealtime stamps (100 MHz), else NULL
 };

@@ -1383,7 +1383,7 @@ int oc_policy_forward_multi(const oc_policy_multi_slot *slots, int32_t n_slots, 
 
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                       int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
-                      float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
+                      float *d_values, int32_t *d_reward, int32_t *d_done, void *d_records, int sample_mode, uint32_t seed, uint32_t counter0,
                       const int32_t *d_row_select, void *stream) {
     if (!e || !d_obs || !d_actions || !d_reward || !d_done || T < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: NULL pointer or negative T");
@@ -1392,7 +1392,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
     if (shp[0] != 2 || shp[4] != OC_POLICY_C) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_rollout: the fused policy kernel reads 2-player observations");
     if (!shape || shp[2] != shape->width || shp[3] != shape->height)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout: the networks' grid does not match the engine's");
-    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
+    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4], rec_slot = n * oc_state_record_bytes(e);
     const OcDeviceScope on_device(oc_device_id(e));       // once for the whole rollout; the per-step calls then find it current
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: cannot make device %d current", oc_device_id(e));
     // ONE launch per step: the env step folded into the policy launch (see fold_* above) wherever the shapes allow it -- 3-digit
@@ -1405,7 +1405,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
         int32_t *cnt = nullptr, *expd = nullptr, groups = 0;
         const oc_dev::StepArgs *tmpl = nullptr;
         oc_dev::StepArgs probe;
-        if (want && T > 0 && shape->digits == 3 && !d_row_select && n_tiles > 0 &&
+        if (want && T > 0 && shape->digits == 3 && !d_row_select && !d_records && n_tiles > 0 &&
             oc_internal_fold_args(e, d_actions, d_obs, d_reward, d_done, &probe, &fp.lds_need) == OC_OK &&
             fp.lds_need <= static_cast<size_t>(staging_bytes(static_cast<int>(shp[2] * shp[3] * shp[4]))) &&
             oc_internal_fold_workspace(e, &cnt, &expd, &groups, &tmpl) == OC_OK) {
@@ -1441,15 +1441,16 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
                                        d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
                                        counter0 + static_cast<uint32_t>(t), nullptr, d_row_select ? d_row_select + t * rows : nullptr, stream))
             return rc;
-        if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n, stream)) return rc;
+        if (int rc = oc_step(e, act_t, OC_ACT_I32, obs_next, d_reward + k * rows, d_done + k * n,
+                             d_records ? static_cast<char *>(d_records) + (t + 1) * rec_slot : nullptr, stream)) return rc;
     }
     return OC_OK;
 }
 
 int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                             int32_t n_tiles, int64_t T, int8_t *d_obs, int32_t *d_actions, float *d_action_logp, float *d_values,
-                            int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0, const int32_t *d_choice,
-                            int32_t *d_index_ws, int32_t *d_count_ws, void *stream) {
+                            int32_t *d_reward, int32_t *d_done, void *d_records, int sample_mode, uint32_t seed, uint32_t counter0,
+                            const int32_t *d_choice, int32_t *d_index_ws, int32_t *d_count_ws, void *stream) {
     if (!e || !d_obs || !d_actions || !d_reward || !d_done || !d_choice || !d_index_ws || !d_count_ws || T < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout_mixed: NULL pointer or negative T");
     int64_t shp[5];
@@ -1457,7 +1458,7 @@ int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const vo
     if (shp[0] != 2 || shp[4] != OC_POLICY_C) return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_rollout_mixed: the fused policy kernel reads 2-player observations");
     if (!shape || shp[2] != shape->width || shp[3] != shape->height)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_rollout_mixed: the networks' grid does not match the engine's");
-    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4];
+    const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4], rec_slot = n * oc_state_record_bytes(e);
     const OcDeviceScope on_device(oc_device_id(e));
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout_mixed: cannot make device %d current", oc_device_id(e));
     // every step's rows sorted by who plays them, for all steps at once: list 2t + side holds row ids side * N + kitchen
@@ -1470,7 +1471,8 @@ int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const vo
                                               d_values ? d_values + t * rows : nullptr, act_t, d_action_logp ? d_action_logp + t * rows : nullptr,
                                               nullptr, sample_mode, seed, counter0 + static_cast<uint32_t>(t), nullptr, stream))
             return rc;
-        if (int rc = oc_step(e, act_t, OC_ACT_I32, d_obs + (t + 1) * slot, d_reward + t * rows, d_done + t * n, stream)) return rc;
+        if (int rc = oc_step(e, act_t, OC_ACT_I32, d_obs + (t + 1) * slot, d_reward + t * rows, d_done + t * n,
+                             d_records ? static_cast<char *>(d_records) + (t + 1) * rec_slot : nullptr, stream)) return rc;
     }
     return OC_OK;
 }
@@ -1551,7 +1553,7 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
     const int n = oc_group_size(g);
     if (n < 1 || !slots || T < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL group / slots or negative T");
     std::vector<oc_engine *> eng(n);
-    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n);
+    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n), rec_bytes(n);
     for (int i = 0; i < n; ++i) {
         eng[i] = oc_internal_group_engine(g, i);
         int64_t shp[5];
@@ -1559,9 +1561,14 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
         const oc_group_policy_slot &s = slots[i];
         if (!s.shape || !s.d_packed || !s.d_tiles || !s.d_obs || !s.d_actions || !s.d_reward || !s.d_done)
             return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL pointer in slot %d", i);
+        // (a group may hold engines with 1, 3 or 4 players: their observations are not what the policy kernel reads, and their
+        // action / reward buffers are P x N, not 2 x N)
+        if (shp[0] != 2 || shp[4] != OC_POLICY_C)
+            return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_group_policy_rollout: engine %d has %lld players; the fused policy kernel reads 2-player observations", i, (long long)shp[0]);
         if (shp[2] != s.shape->width || shp[3] != s.shape->height)
             return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: the networks' grid of slot %d does not match its engine's", i);
         kitchens[i] = shp[1]; rows[i] = 2 * shp[1]; slot_bytes[i] = rows[i] * shp[2] * shp[3] * shp[4];
+        rec_bytes[i] = shp[1] * oc_state_record_bytes(eng[i]);
     }
     const OcDeviceScope on_device(oc_device_id(eng[0]));
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_group_policy_rollout: cannot make device %d current", oc_device_id(eng[0]));
@@ -1582,6 +1589,7 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
         std::vector<const void *> act(n);
         std::vector<int8_t *> obs_next(n);
         std::vector<int32_t *> rew(n), done(n);
+        std::vector<void *> recs(n);
         for (int64_t t = 0; t < T; ++t) {
             const int64_t k = in_place ? 0 : t;
             for (int i = 0; i < n; ++i) {
@@ -1590,8 +1598,9 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
                 obs_next[i] = in_place ? slots[i].d_obs : slots[i].d_obs + (t + 1) * slot_bytes[i];
                 rew[i] = slots[i].d_reward + k * rows[i];
                 done[i] = slots[i].d_done + k * kitchens[i];
+                recs[i] = slots[i].d_records ? static_cast<char *>(slots[i].d_records) + (t + 1) * rec_bytes[i] : nullptr;
             }
-            if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream)) return rc;
+            if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), recs.data(), stream)) return rc;
         }
         return OC_OK;
     }
@@ -1615,7 +1624,8 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
             rc = policy(i, t, static_cast<hipStream_t>(policy_streams[i]), cu_budgets ? cu_budgets[i] : 0);
             if (rc == OC_OK)
                 rc = oc_step(eng[i], s.d_actions + k * rows[i], OC_ACT_I32, in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i],
-                             s.d_reward + k * rows[i], s.d_done + k * kitchens[i], policy_streams[i]);
+                             s.d_reward + k * rows[i], s.d_done + k * kitchens[i],
+                             s.d_records ? static_cast<char *>(s.d_records) + (t + 1) * rec_bytes[i] : nullptr, policy_streams[i]);
         }
     }
     for (int i = 0; i < n; ++i) (void)oc_internal_set_cu_budget(eng[i], 0);
@@ -1633,10 +1643,11 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
     const int n = oc_group_size(g);
     if (n < 1 || n > kMaxSlots || !slots || !d_tiles || T < 0)
         return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: NULL group / slots / tiles, negative T or more than %d engines", kMaxSlots);
-    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n);
+    std::vector<int64_t> kitchens(n), rows(n), slot_bytes(n), rec_bytes(n);
     for (int i = 0; i < n; ++i) {
         int64_t shp[5];
         if (int rc = oc_obs_shape(oc_internal_group_engine(g, i), shp)) return rc;
+        rec_bytes[i] = shp[1] * oc_state_record_bytes(oc_internal_group_engine(g, i));
         const oc_group_policy_slot &s = slots[i];
         if (!s.shape || !s.d_packed || !s.d_obs || !s.d_actions || !s.d_reward || !s.d_done)
             return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout_multi: NULL pointer in slot %d", i);
@@ -1650,6 +1661,7 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
     std::vector<const void *> act(n);
     std::vector<int8_t *> obs_next(n);
     std::vector<int32_t *> rew(n), done(n);
+    std::vector<void *> recs(n);
     const PlanesReadNext hint(g);
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
@@ -1667,9 +1679,10 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
             obs_next[i] = in_place ? s.d_obs : s.d_obs + (t + 1) * slot_bytes[i];
             rew[i] = s.d_reward + k * rows[i];
             done[i] = s.d_done + k * kitchens[i];
+            recs[i] = s.d_records ? static_cast<char *>(s.d_records) + (t + 1) * rec_bytes[i] : nullptr;
         }
         if (int rc = oc_policy_forward_multi(ms.data(), n, d_tiles, n_tiles, tiles_per_workgroup, waves_per_workgroup, sample_mode, counter0 + static_cast<uint32_t>(t), nullptr, stream)) return rc;
-        if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), stream)) return rc;
+        if (int rc = oc_group_step(g, act.data(), OC_ACT_I32, obs_next.data(), rew.data(), done.data(), recs.data(), stream)) return rc;
     }
     return OC_OK;
 }

@@ -127,15 +127,29 @@ class OvercookedEngine:
             a = a.contiguous()
         return a, (native.OC_ACT_I64 if a.dtype == torch.int64 else native.OC_ACT_I32)
 
-    def step(self, actions, obs=None, reward=None, done=None):
+    def _records_arg(self, records, steps=None):
+        """-> (pointer or None, bytes between consecutive steps' blocks) of a record destination: int32 [N, rec/4] for one step,
+        [steps, N, rec/4] for a rollout; written by the step launches themselves (oc_step's d_records)."""
+        if records is None:
+            return None, 0
+        per_step = self.num_kitchens * self.record_bytes
+        want = per_step if steps is None else steps * per_step
+        if (records.dtype != torch.int32 or not records.is_contiguous() or records.device != self.device
+                or records.numel() * 4 != want or records.data_ptr() % 16):
+            raise ValueError(f"records must be a contiguous, 16-byte aligned int32 tensor of {want} bytes on {self.device}")
+        return _ptr(records), per_step
+
+    def step(self, actions, obs=None, reward=None, done=None, records=None):
         """One fused transition+featurisation launch on the current torch stream (no host sync).
         actions: int32/int64 [P, N] or [P, N, 1].  Outputs go to the engine's own buffers unless
-        explicit destination tensors (same shapes/dtypes) are given."""
+        explicit destination tensors (same shapes/dtypes) are given.  records: optional int32 [N, rec/4] -- the same launch
+        also writes the post-step state records there (the trajectory's compact record slot; no export_states pass)."""
         a, dt = self._actions(actions)
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
         done = self.done if done is None else done
-        native.check(self._L.oc_step(self._handle, _ptr(a), dt, _ptr(obs), _ptr(reward), _ptr(done), self._stream()))
+        rec, _ = self._records_arg(records)
+        native.check(self._L.oc_step(self._handle, _ptr(a), dt, _ptr(obs), _ptr(reward), _ptr(done), rec, self._stream()))
         return obs, reward, done
 
     def observe(self, obs=None):
@@ -170,10 +184,11 @@ class OvercookedEngine:
         self.episode_control(timesteps=ts.to(torch.int32))
         return ts
 
-    def rollout(self, actions, steps, obs=None, reward=None, done=None):
+    def rollout(self, actions, steps, obs=None, reward=None, done=None, records=None):
         """`steps` consecutive launches enqueued from C.  actions [T_act, P, N] are cycled.
         obs/reward/done may carry a leading time axis of length `steps` (time-major trajectory
-        buffers, written in place) or be single-step buffers that are overwritten."""
+        buffers, written in place) or be single-step buffers that are overwritten.  records: optional int32
+        [steps, N, rec/4], step t's post-step records written by step t's launch."""
         if actions.dim() < 3 or actions[0].numel() != self.num_players * self.num_kitchens:
             raise ValueError(f"rollout actions must be [T_act, P, N] with P*N = {self.num_players * self.num_kitchens}")
         t_act = actions.shape[0]
@@ -188,11 +203,12 @@ class OvercookedEngine:
         so = obs[0].numel() if obs.dim() == 6 else 0
         sr = reward[0].numel() if reward.dim() == 3 else 0
         sd = done[0].numel() if done.dim() == 2 else 0
+        rec, rec_stride = self._records_arg(records, steps)
         native.check(self._L.oc_rollout(self._handle, _ptr(flat), dt, t_act, steps, _ptr(obs), so, _ptr(reward), sr,
-                                        _ptr(done), sd, self._stream()))
+                                        _ptr(done), sd, rec, rec_stride, self._stream()))
         return obs, reward, done
 
-    def rollout_fused(self, steps, actions=None, seed=0, t0=0, obs=None, reward=None, done=None):
+    def rollout_fused(self, steps, actions=None, seed=0, t0=0, obs=None, reward=None, done=None, records=None):
         """The whole rollout in one launch (state stays on chip between steps).  actions: tape [T_act, P, N]
         used cyclically, or None for the built-in counter-hash stream (`synthetic_actions` reproduces it).
         obs/reward/done may carry a leading time axis of length `steps` (filled slot by slot) or be single-step
@@ -212,9 +228,10 @@ class OvercookedEngine:
         so = obs[0].numel() if obs.dim() == 6 else 0
         sr = reward[0].numel() if reward.dim() == 3 else 0
         sd = done[0].numel() if done.dim() == 2 else 0
+        rec, rec_stride = self._records_arg(records, steps)
         native.check(self._L.oc_rollout_fused(self._handle, _ptr(flat) if flat is not None else None, dt, t_act, steps,
                                               seed & 0xFFFFFFFF, t0 & 0xFFFFFFFF, _ptr(obs), so, _ptr(reward), sr,
-                                              _ptr(done), sd, self._stream()))
+                                              _ptr(done), sd, rec, rec_stride, self._stream()))
         return obs, reward, done
 
     @staticmethod

@@ -70,9 +70,10 @@ class EngineGroup:
         return self._L.oc_group_build_info(self._handle).decode()
 
     # ------------------------------------------------------------------ hot path
-    def step(self, actions, obs=None, reward=None, done=None):
+    def step(self, actions, obs=None, reward=None, done=None, records=None):
         """actions: one int32/int64 `[P, N_i]` (or `[P, N_i, 1]`) tensor per engine, all of one dtype.  Outputs go to
-        each engine's own buffers unless explicit per-engine destination lists are given.  One launch, no host sync."""
+        each engine's own buffers unless explicit per-engine destination lists are given.  records: optional list of int32
+        `[N_i, rec_i/4]` tensors (entries may be None) that receive the post-step state records.  One launch, no host sync."""
         prepared = [e._actions(a) for e, a in zip(self.engines, actions)]
         if len(prepared) != len(self.engines):
             raise ValueError("one action tensor per engine")
@@ -81,7 +82,11 @@ class EngineGroup:
             raise ValueError("the action tensors of a group step must share one dtype")
         acts = [a for a, _ in prepared]
         tabs = [self._own[i] if given is None else _table(given) for i, given in enumerate((obs, reward, done))]
-        native.check(self._L.oc_group_step(self._handle, _table(acts), dtypes.pop(), tabs[0], tabs[1], tabs[2], self._stream()))
+        rec_tab = None
+        if records is not None:
+            ptrs = [e._records_arg(r)[0] for e, r in zip(self.engines, records)]
+            rec_tab = (ctypes.c_void_p * len(ptrs))(*[p.value if p is not None else None for p in ptrs])
+        native.check(self._L.oc_group_step(self._handle, _table(acts), dtypes.pop(), tabs[0], tabs[1], tabs[2], rec_tab, self._stream()))
         pick = lambda given, name: [getattr(e, name) for e in self.engines] if given is None else list(given)
         return pick(obs, "obs"), pick(reward, "reward"), pick(done, "done")
 
@@ -140,6 +145,9 @@ class GroupPairedRollout:
         self.threads = [threads] * n_eng if isinstance(threads, int) else list(threads)
         self.segments, rows_all, work = [], [], []
         for i, (e, nt, th) in enumerate(zip(group.engines, self.nets, self.threads)):
+            if e.num_players != 2:
+                raise native.OvercookedNativeError(-2, f"engine {i} has {e.num_players} players: the fused policy kernel reads 2-player "
+                                                       "observations, and the paired rollout's action / reward buffers are [2, N]")
             segs = pairing_segments(th, n_conventions)
             g, n = len(segs), e.num_kitchens
             if n != g * th:
@@ -183,7 +191,7 @@ class GroupPairedRollout:
         cus_total = torch.cuda.get_device_properties(self.group.device).multi_processor_count
         return [PolicyPlan(nt, 2 * e.num_kitchens, rows, rows_per_tile=-cus_total) for e, nt, rows in zip(self.group.engines, self.nets, rows_all)]
 
-    def _slots(self, obs, actions, logp, values, reward, done):
+    def _slots(self, obs, actions, logp, values, reward, done, records=None):
         p = lambda t: _vp(t.data_ptr()) if t is not None else None
         slots = (native.OcGroupPolicySlot * len(self.group))()
         for i, (nt, plan) in enumerate(zip(self.nets, self.plans)):
@@ -192,10 +200,11 @@ class GroupPairedRollout:
             s.d_packed, s.n_nets, s.d_tiles, s.n_tiles = p(nt.image), nt.n_nets, p(plan.tiles), plan.n_tiles
             s.d_obs, s.d_actions, s.d_action_logp, s.d_values = p(obs[i]), p(actions[i]), p(logp[i]), p(values[i])
             s.d_reward, s.d_done = p(reward[i]), p(done[i])
+            s.d_records = p(records[i]) if records is not None else None
         return slots
 
-    def _run(self, T, in_place, obs, actions, logp, values, reward, done):
-        slots = self._slots(obs, actions, logp, values, reward, done)
+    def _run(self, T, in_place, obs, actions, logp, values, reward, done, records=None):
+        slots = self._slots(obs, actions, logp, values, reward, done, records)
         sample, seed, c0 = 0 if self.deterministic else 1, self.seed & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF
         if self._one_launch:
             native.check(self._L.oc_group_policy_rollout_multi(
@@ -221,8 +230,9 @@ class GroupPairedRollout:
         for t in trajs:
             t.start()
         none = [None] * len(trajs)
+        # (trajectories built with store_states=True get their compact records from the env launches themselves)
         self._run(T, False, [t.obs for t in trajs], [t.actions for t in trajs], logps or none, values or none,
-                  [t.reward for t in trajs], [t.done for t in trajs])
+                  [t.reward for t in trajs], [t.done for t in trajs], [t.records for t in trajs])
         for t in trajs:
             t.t = T
         return trajs

@@ -119,7 +119,7 @@ class MixedPlayRollout:
         native.check(native.lib().oc_policy_rollout_mixed(
             e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
             self.plan.n_tiles, T, _ptr(self.traj.obs), _ptr(self.traj.actions), _ptr(self.logp), _ptr(self.values),
-            _ptr(self.traj.reward), _ptr(self.traj.done), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF,
+            _ptr(self.traj.reward), _ptr(self.traj.done), _ptr(self.traj.records), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF,
             self.draws_done & 0xFFFFFFFF, _ptr(self.choice), _ptr(self.index), _ptr(self.count), _stream(e.device)))
         self.draws_done += T
         self.traj.t = T

@@ -71,7 +71,8 @@ class OcGroupPolicySlot(ctypes.Structure):
     """struct oc_group_policy_slot"""
     _fields_ = [("shape", ctypes.POINTER(OcPolicyShape)), ("d_packed", ctypes.c_void_p), ("n_nets", ctypes.c_int32),
                 ("d_tiles", ctypes.c_void_p), ("n_tiles", ctypes.c_int32), ("d_obs", ctypes.c_void_p), ("d_actions", ctypes.c_void_p),
-                ("d_action_logp", ctypes.c_void_p), ("d_values", ctypes.c_void_p), ("d_reward", ctypes.c_void_p), ("d_done", ctypes.c_void_p)]
+                ("d_action_logp", ctypes.c_void_p), ("d_values", ctypes.c_void_p), ("d_reward", ctypes.c_void_p), ("d_done", ctypes.c_void_p),
+                ("d_records", ctypes.c_void_p)]
 
 
 class OcPolicyMultiSlot(ctypes.Structure):
@@ -158,14 +159,14 @@ def lib():
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     L.oc_create.argtypes = [ctypes.POINTER(OcLayoutParams), i64, i32, ctypes.POINTER(vp)]
     L.oc_destroy.argtypes = [vp]
-    L.oc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.oc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.oc_observe.argtypes = [vp, vp, vp]
     L.oc_reset_all.argtypes = [vp, vp, vp]
     L.oc_episode_control.argtypes = [vp, vp, vp, vp]
-    L.oc_rollout.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, i64, vp]
+    L.oc_rollout.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
     L.oc_rollout_timed.argtypes = [vp, vp, i32, i64, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     u32 = ctypes.c_uint32
-    L.oc_rollout_fused.argtypes = [vp, vp, i32, i64, i64, u32, u32, vp, i64, vp, i64, vp, i64, vp]
+    L.oc_rollout_fused.argtypes = [vp, vp, i32, i64, i64, u32, u32, vp, i64, vp, i64, vp, i64, vp, i64, vp]
     L.oc_synthetic_action.argtypes = [u32, u32, u32, u32]
     L.oc_synthetic_action.restype = u32
     L.oc_encode_states.argtypes = [vp, vp, i64, vp, vp]
@@ -205,8 +206,8 @@ def lib():
     L.oc_policy_forward.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp]
     L.oc_partition_rows.argtypes = [vp, i64, i64, i64, vp, vp, vp]
     L.oc_policy_forward_gather.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, i64, vp, vp, vp, vp, i32, u32, u32, vp, vp]
-    L.oc_policy_rollout_mixed.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp, vp]
-    L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
+    L.oc_policy_rollout_mixed.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, vp, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp, vp]
+    L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
     L.oc_exp_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
     L.oc_exp_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     L.oc_exp_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
@@ -236,7 +237,7 @@ def lib():
     L.oc_group_destroy.argtypes = [vp]
     L.oc_group_size.argtypes = [vp]
     L.oc_group_size.restype = ctypes.c_int32
-    L.oc_group_step.argtypes = [vp, pvp, i32, pvp, pvp, pvp, vp]
+    L.oc_group_step.argtypes = [vp, pvp, i32, pvp, pvp, pvp, pvp, vp]
     L.oc_group_observe.argtypes = [vp, pvp, vp]
     L.oc_group_rollout_timed.argtypes = [vp, pvp, i32, i64, i64, pvp, pvp, pvp, vp, ctypes.POINTER(ctypes.c_float)]
     L.oc_group_set_tuning.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), i32, i32]

@@ -108,7 +108,7 @@ class FusedPairedRollout:
         self.draw.add_(1)
         self.engine.step(self.actions)
 
-    def _native(self, T, in_place, obs, actions, logp, values, reward, done):
+    def _native(self, T, in_place, obs, actions, logp, values, reward, done, records=None):
         import ctypes
         from . import native
         from .fused_policy import _ptr, _shape, _stream
@@ -116,7 +116,7 @@ class FusedPairedRollout:
         native.check(native.lib().oc_policy_rollout(
             e._handle, ctypes.byref(_shape(nets.W, nets.H, 6, nets.digits)), _ptr(nets.image), nets.n_nets, _ptr(self.plan.tiles),
             self.plan.n_tiles, int(T), 1 if in_place else 0, _ptr(obs), _ptr(actions), _ptr(logp), _ptr(values), _ptr(reward), _ptr(done),
-            0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, None, _stream(e.device)))
+            _ptr(records), 0 if self.deterministic else 1, int(self.seed) & 0xFFFFFFFF, self.steps_done & 0xFFFFFFFF, None, _stream(e.device)))
         self.steps_done += int(T)
 
     def step(self, steps: int = 1):
@@ -153,6 +153,7 @@ class FusedPairedRollout:
                 raise ValueError(f"{name} must be a contiguous float32 tensor of shape {tuple(traj.actions.shape)}")
         if values is not None and self.values is None:
             raise ValueError("this rollout was built without critics")
-        self._native(traj.T, False, traj.obs, traj.actions, logp, values, traj.reward, traj.done)
+        # (a trajectory built with store_states=True gets slot t+1 of its compact records from step t's env launch)
+        self._native(traj.T, False, traj.obs, traj.actions, logp, values, traj.reward, traj.done, traj.records)
         traj.t = traj.T
         return traj

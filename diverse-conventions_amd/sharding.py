@@ -79,27 +79,32 @@ def local_segments(threads_total: int, n_conventions: int, world: int, rank: int
 class TrajectoryExchange:
     """All-gather of compact time-major trajectory shards: ONE collective per update.
 
-    `gather_trajectory` packs the four compact fields of a rank's rollout into one flat int32 buffer
-    [records | actions | reward | done] (one concatenation pass over 4S+16 bytes per kitchen-step), issues a single
-    `all_gather_into_tensor` on it (RCCL over xGMI on the GPU box, gloo in the CPU tests: both take flat 1-D buffers)
-    and hands back per-field views of the result, peers in rank order: [world, T, ...].  Shards must be equal-sized
+    `gather_buffer` sends a `TrajectoryBuffer(store_states=True)`'s flat int32 `wire` buffer -- [records | actions | reward | done],
+    the layout of `trajectory.wire_layout`, filled in place by the rollout's own launches -- through a single
+    `all_gather_into_tensor` AS IT IS (RCCL over xGMI on the GPU box, gloo in the CPU tests: both take flat 1-D buffers; no
+    concatenation pass, no per-field copies) and hands back per-field views of the result, peers in rank order: [world, ...].
+    `gather_trajectory` does the same for four loose tensors at the price of one concatenation pass.  Shards must be equal-sized
     (use a kitchen count divisible by the world size); errors of the collective propagate."""
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None, always_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.collectives = 0                      # all-gathers issued so far (one per gather_trajectory)
+        self.collectives = 0                      # all-gathers issued so far (one per gather_trajectory / gather_buffer)
         # a single rank needs no collective; always_collective issues it anyway (how a 1-GPU box exercises the RCCL call)
         self.always_collective = bool(always_collective) and dist.is_initialized()
 
-    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
-        """[...] -> [world, ...], rank r's tensor at index r."""
+    def all_gather(self, local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[...] -> [world, ...], rank r's tensor at index r.  `out`: optional flat destination of world * numel elements
+        (a persistent receive buffer: one allocation for all updates)."""
         local = local.contiguous()
         if self.world == 1 and not self.always_collective:
             return local.unsqueeze(0)
-        out = torch.empty((self.world * local.numel(),), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.view(-1), group=self.group)
+        if out is None:
+            out = torch.empty((self.world * local.numel(),), dtype=local.dtype, device=local.device)
+        elif out.numel() != self.world * local.numel() or out.dtype != local.dtype or not out.is_contiguous():
+            raise ValueError("out must be a contiguous buffer of world * numel elements of the shard's dtype")
+        dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=self.group)
         self.collectives += 1
         return out.view((self.world,) + tuple(local.shape))
 
@@ -109,9 +114,27 @@ class TrajectoryExchange:
             raise ValueError("compact trajectory fields are int32 (records as int32 words)")
         return t.contiguous().view(-1)
 
+    def gather_buffer(self, traj, out: Optional[torch.Tensor] = None):
+        """traj: a TrajectoryBuffer built with store_states=True (every rank with the same T, P, n, layout)
+        -> dict of [world, ...] views of ONE gathered buffer: records [world, T+1, n, rec/4], actions / reward [world, T, P, n],
+        done [world, T, n].  The shard's `wire` buffer is the send buffer itself."""
+        from .trajectory import wire_layout
+        if traj.wire is None:
+            raise ValueError("gather_buffer needs a TrajectoryBuffer(store_states=True): its fields live in one wire buffer")
+        fields, words = wire_layout(traj.T, traj.P, traj.engine.num_kitchens, traj.engine.record_bytes // 4)
+        assert words == traj.wire.numel()
+        got = self.all_gather(traj.wire, out)     # [world, words]
+        res = {}
+        for name, (off, shape) in fields.items():
+            n = 1
+            for d in shape:
+                n *= d
+            res[name] = got[:, off:off + n].view((got.shape[0],) + shape)
+        return res
+
     def gather_trajectory(self, records, actions, reward, done):
-        """records int32 [T, n, rec/4]; actions int32 [T, P, n]; reward int32 [T, n]; done int32 [T, n]
-        -> dict of [world, ...] views of ONE gathered buffer (peer r's shard at index r)."""
+        """Loose fields (one concatenation pass; prefer gather_buffer): records int32 [T, n, rec/4]; actions int32 [T, P, n];
+        reward int32 [T, n]; done int32 [T, n] -> dict of [world, ...] views of ONE gathered buffer (peer r's shard at index r)."""
         fields = (("records", records), ("actions", actions), ("reward", reward), ("done", done))
         flat = [self._as_words(t) for _, t in fields]
         sizes = [f.numel() for f in flat]

@@ -61,7 +61,7 @@ extern "C" {
 #define OC_MAX_TILES 255
 #define OC_MAX_PLAYERS 4
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 5
+#define OC_ABI_VERSION 6
 
 typedef enum {
     OC_OK = 0,
@@ -99,9 +99,12 @@ int oc_destroy(oc_engine *e);
 
 /* replaces Manager::step (mgr.cpp:208-211), but stream-ordered instead of blocking.
  * One fused launch: joint interact/move/collision transition, pot timers, horizon auto-reset,
- * reward, done, and the 20-channel lossless_state_encoding of the post-step state for both viewers. */
+ * reward, done, and the 20-channel lossless_state_encoding of the post-step state for both viewers.
+ * d_records (may be NULL): trajectory recording without an extra pass -- the same launch also writes the POST-step state records
+ * of all kitchens there ([N][oc_state_record_bytes()], 16-byte aligned; what oc_export_states would copy out after the step): the
+ * compact trajectory of the exchange (oc_encode_trajectory re-featurises it on the receiver). */
 int oc_step(oc_engine *e, const void *d_actions, int action_dtype, int8_t *d_obs, int32_t *d_reward,
-            int32_t *d_done, void *stream);
+            int32_t *d_done, void *d_records, void *stream);
 
 /* Observation of the current state without stepping: what OvercookedMadrona.n_reset()/get_obs()
  * return (envs/overcooked2_env.py:103-114,127-128 -- n_reset re-reads, it does not reset). */
@@ -120,10 +123,11 @@ int oc_episode_control(oc_engine *e, const int32_t *d_reset_mask, const int32_t 
 /* T consecutive steps enqueued from C (no host work between launches): actions [T_act][P][N] are
  * consumed cyclically (step t uses slice t % T_act); obs/reward/done are overwritten every step
  * unless the *_step_stride (in elements, may be 0) says to advance per step.  Rollout driver for
- * bench.py and for trajectory collection straight into time-major buffers. */
+ * bench.py and for trajectory collection straight into time-major buffers.  d_records (may be NULL): step t's post-step
+ * records go to d_records + t * records_step_stride BYTES (a multiple of 16), see oc_step. */
 int oc_rollout(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T,
                int8_t *d_obs, int64_t obs_step_stride, int32_t *d_reward, int64_t reward_step_stride,
-               int32_t *d_done, int64_t done_step_stride, void *stream);
+               int32_t *d_done, int64_t done_step_stride, void *d_records, int64_t records_step_stride, void *stream);
 
 /* Same as oc_rollout but brackets the T launches with hipEvents on `stream`, synchronises, and
  * returns the elapsed milliseconds (kernel-time basis for the roofline figure). */
@@ -137,10 +141,11 @@ int oc_rollout_timed(oc_engine *e, const void *d_actions, int action_dtype, int6
  * base + t * *_step_stride (obs stride in bytes, reward/done in elements; 0 = overwrite in place).
  * d_actions: tape [T_act][P][N] used cyclically, or NULL for the built-in counter-hash stream
  * action = oc_synthetic_action(rng_seed, kitchen, rng_t0 + t, player) (uniform on 0..5).
+ * d_records / records_step_stride (bytes): as oc_rollout -- the records leave the LDS-resident state once per step.
  * Results are identical to T calls of oc_step with the same actions. */
 int oc_rollout_fused(oc_engine *e, const void *d_actions, int action_dtype, int64_t T_act, int64_t T, uint32_t rng_seed,
                      uint32_t rng_t0, int8_t *d_obs, int64_t obs_step_stride, int32_t *d_reward, int64_t reward_step_stride,
-                     int32_t *d_done, int64_t done_step_stride, void *stream);
+                     int32_t *d_done, int64_t done_step_stride, void *d_records, int64_t records_step_stride, void *stream);
 uint32_t oc_synthetic_action(uint32_t seed, uint32_t kitchen, uint32_t step, uint32_t player);
 
 /* Featurise n externally supplied state records (device pointer, record format above) without
@@ -171,7 +176,8 @@ int oc_group_create(oc_engine *const *engines, int32_t n_engines, oc_group **out
 int oc_group_destroy(oc_group *g);                    /* the engines belong to the caller: they stay alive, and must outlive the group */
 int32_t oc_group_size(const oc_group *g);
 int oc_group_step(oc_group *g, const void *const *d_actions, int action_dtype, int8_t *const *d_obs, int32_t *const *d_reward,
-                  int32_t *const *d_done, void *stream);
+                  int32_t *const *d_done, void *const *d_records /* NULL, or a table of per-engine record destinations (entries may be NULL) */,
+                  void *stream);
 int oc_group_observe(oc_group *g, int8_t *const *d_obs, void *stream);
 /* T joint steps enqueued from C and bracketed by hipEvents on `stream` (the group counterpart of oc_rollout_timed):
  * engine i consumes its action tape d_actions[i] = [T_act][P][N_i] cyclically; outputs overwritten in place. */

@@ -193,6 +193,7 @@ typedef struct {
     float *d_values;           /* may be NULL */
     int32_t *d_reward;
     int32_t *d_done;
+    void *d_records;           /* may be NULL; as oc_policy_rollout's */
 } oc_group_policy_slot;
 int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, int64_t T, int in_place, int sample_mode, uint32_t seed,
                             uint32_t counter0, void *stream);
@@ -209,20 +210,23 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
  * NULL, d_reward int32 [T][P][N], d_done int32 [T][N]; step t reads slot t and writes slot t+1.  in_place != 0: one
  * slot of each, overwritten every step.  The draw counter of step t is counter0 + t.  d_row_select: NULL, or int32 [T][2N]
  * per-row policy choices of every step (always time-major), as oc_policy_forward takes them for one step: the whole
- * mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) is then one call. */
+ * mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) is then one call.
+ * d_records: NULL, or the compact trajectory [T+1][N][oc_state_record_bytes()] (16-byte aligned, always time-major): the env launch
+ * of step t writes the post-step records to slot t+1 (oc_step's d_records); slot 0 is the caller's (oc_export_states before the call). */
 int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                       int32_t n_tiles, int64_t T, int in_place, int8_t *d_obs, int32_t *d_actions, float *d_action_logp,
-                      float *d_values, int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0,
+                      float *d_values, int32_t *d_reward, int32_t *d_done, void *d_records, int sample_mode, uint32_t seed, uint32_t counter0,
                       const int32_t *d_row_select, void *stream);
 /* The mixed-play collection of XDPlayer.collect_mp_episode (train/XD/xd_player.py:232-356) as ONE call: T steps, always time-major
  * (buffers as oc_policy_rollout with in_place = 0), d_choice int32 [T][2N] = which of the two candidate policies plays row
  * player * N + kitchen at step t.  The call partitions every step's rows by choice (oc_partition_rows into the caller's workspaces
  * d_index_ws int32 [T][2N], d_count_ws int32 [T][2][2]) and runs, per step, one oc_policy_forward_gather + one oc_step.
- * d_tiles: gather tiles {side, choice, net, flags | OC_POLICY_TILE_GATHER}: typically 8 (2 sides x 2 choices x actor / critic). */
+ * d_tiles: gather tiles {side, choice, net, flags | OC_POLICY_TILE_GATHER}: typically 8 (2 sides x 2 choices x actor / critic).
+ * d_records: as oc_policy_rollout's. */
 int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int32_t *d_tiles,
                             int32_t n_tiles, int64_t T, int8_t *d_obs, int32_t *d_actions, float *d_action_logp, float *d_values,
-                            int32_t *d_reward, int32_t *d_done, int sample_mode, uint32_t seed, uint32_t counter0, const int32_t *d_choice,
-                            int32_t *d_index_ws, int32_t *d_count_ws, void *stream);
+                            int32_t *d_reward, int32_t *d_done, void *d_records, int sample_mode, uint32_t seed, uint32_t counter0,
+                            const int32_t *d_choice, int32_t *d_index_ws, int32_t *d_count_ws, void *stream);
 
 
 

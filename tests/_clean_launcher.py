@@ -14,6 +14,8 @@ def main():
             continue
         req = json.loads(line)
         env = dict(os.environ)
+        for k in req.get("drop_env") or ():
+            env.pop(k, None)
         env.update(req.get("env") or {})
         try:
             p = subprocess.run(req["cmd"], env=env, cwd=req.get("cwd"), capture_output=True, text=True, timeout=req.get("timeout", 600))

@@ -16,22 +16,19 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 params = get_base_layout_params("coordination_ring", 200)
 n, T = 384, 12
 eng = OvercookedEngine(params, n, 0)
-r4 = eng.record_bytes // 4
-rec = torch.zeros((T, n, r4), dtype=torch.int32, device="cuda")
-rew = torch.zeros((T, n), dtype=torch.int32, device="cuda")
-done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+from diverse_conventions_amd import TrajectoryBuffer
+traj = TrajectoryBuffer(eng, T, store_states=True)                 # records / actions / reward / done: views of ONE wire buffer
 acts = torch.randint(0, 6, (T, 2, n), device="cuda", dtype=torch.int32)
-obs = torch.zeros((T,) + tuple(eng.obs.shape), dtype=torch.int8, device="cuda")
 for t in range(T):
-    eng.export_states(out=rec[t])
-    obs[t].copy_(eng.obs)
-    _, r, d = eng.step(acts[t])
-    rew[t].copy_(r[0]); done[t].copy_(d)
+    traj.step(acts[t])                                             # one launch per step, the records written by the step kernel
 ex = TrajectoryExchange(always_collective=True)
-got = ex.gather_trajectory(rec, acts, rew, done)
-ok = ex.collectives == 1 and got["records"].shape == (1, T, n, r4)
-ok &= bool(torch.equal(got["records"][0], rec) and torch.equal(got["actions"][0], acts) and torch.equal(got["reward"][0], rew))
-ok &= bool(torch.equal(ex.featurize_all(eng, got["records"]), obs))
+got = ex.gather_buffer(traj)                                       # the wire buffer itself through all_gather_into_tensor (RCCL)
+ok = ex.collectives == 1 and got["records"].shape == (1, T + 1, n, eng.record_bytes // 4)
+ok &= bool(torch.equal(got["records"][0], traj.records) and torch.equal(got["actions"][0], acts) and torch.equal(got["reward"][0], traj.reward))
+ok &= bool(torch.equal(got["done"][0], traj.done) and torch.equal(ex.featurize_all(eng, got["records"]), traj.obs))
+# loose fields (one concatenation pass) give the same bytes
+loose = ex.gather_trajectory(traj.records[:T].contiguous(), acts, traj.reward[:, 0].contiguous(), traj.done)
+ok &= ex.collectives == 2 and bool(torch.equal(loose["records"][0], traj.records[:T]) and torch.equal(loose["done"][0], traj.done))
 segs = pairing_segments(n // 3, 1)
 scores = segment_scores(torch.arange(n, device="cuda", dtype=torch.float32), segs)
 ok &= bool(torch.allclose(scores.cpu(), torch.tensor([(n // 3 - 1) / 2 + i * (n // 3) for i in range(3)])))

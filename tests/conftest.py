@@ -33,8 +33,8 @@ class CleanLauncher:
         self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_clean_launcher.py")], stdin=subprocess.PIPE,
                                      stdout=subprocess.PIPE, text=True, cwd=ROOT)
 
-    def run(self, cmd, env=None, timeout=600):
-        self.proc.stdin.write(json.dumps({"cmd": list(cmd), "env": env or {}, "cwd": ROOT, "timeout": timeout}) + "\n")
+    def run(self, cmd, env=None, timeout=600, drop_env=()):
+        self.proc.stdin.write(json.dumps({"cmd": list(cmd), "env": env or {}, "drop_env": list(drop_env), "cwd": ROOT, "timeout": timeout}) + "\n")
         self.proc.stdin.flush()
         return json.loads(self.proc.stdout.readline())
 

@@ -91,13 +91,22 @@ def test_config4_one_gpu_share(layout_params):
     eng = OvercookedEngine(params, n, 0)
     ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=critic_of, seed=5)
     assert len(ro.segments) == G
-    traj = TrajectoryBuffer(eng, T)
+    traj = TrajectoryBuffer(eng, T, store_states=True)        # compact records written by the env launches themselves (oc_step's d_records)
     logp = torch.zeros((T, 2, n), device="cuda")
     values = torch.zeros((T, 2, n), device="cuda")
     ro.collect(traj, logp=logp, values=values)
     acts = _check_env_against_oracle(params, traj, T)
     assert len(np.unique(acts)) == 6
     _check_policies(ro, traj, logp, values, actors_sd, critics_sd, critic_of, T, shape)
+    # the recorded trajectory IS the wire buffer: one flat int32 allocation in the exchange's order, every slot the state its
+    # observation slot shows, the last one the engine's current state
+    assert traj.records.data_ptr() == traj.wire.data_ptr() and traj.done.data_ptr() + traj.done.numel() * 4 <= traj.wire.data_ptr() + traj.wire.numel() * 4
+    assert torch.equal(traj.records[T], eng.export_states())
+    ex1 = TrajectoryExchange()
+    got1 = ex1.gather_buffer(traj)                            # world 1: views of the wire buffer itself, no copy
+    assert got1["records"].shape == (1, T + 1, n, 52) and got1["records"].data_ptr() == traj.wire.data_ptr()
+    assert torch.equal(ex1.featurize_all(eng, got1["records"]), traj.obs)
+    assert torch.equal(got1["actions"][0], traj.actions) and torch.equal(got1["reward"][0], traj.reward) and torch.equal(got1["done"][0], traj.done)
 
     # ---- (b) the compact exchange of that trajectory between two shards, receivers re-featurise
     world, half = 2, n // 2

@@ -66,7 +66,7 @@ def test_group_rejects_bad_arguments():
     arr = (ctypes.c_void_p * 9)()
     assert L.oc_group_create(arr, 9, ctypes.byref(out)) == -1 and b"1..8" in L.oc_last_error()
     assert L.oc_group_create(arr, 1, ctypes.byref(out)) == -1 and b"NULL" in L.oc_last_error()
-    assert L.oc_group_step(None, None, 0, None, None, None, None) == -1
+    assert L.oc_group_step(None, None, 0, None, None, None, None, None) == -1
     assert L.oc_group_size(None) == 0 and L.oc_group_destroy(None) == 0
 
 
@@ -298,7 +298,7 @@ def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deter
     engines = make()
     grp = EngineGroup(engines)
     gro = GroupPairedRollout(grp, nets, threads, k, critic_nets=critic_of, deterministic=deterministic, seed=seed, partition=partition)
-    trajs = [TrajectoryBuffer(e, T) for e in engines]
+    trajs = [TrajectoryBuffer(e, T, store_states=(i != 1)) for i, e in enumerate(engines)]     # (a group may record some engines only)
     lps = [torch.zeros((T, 2, e.num_kitchens), device="cuda") for e in engines]
     vas = [torch.zeros((T, 2, e.num_kitchens), device="cuda") for e in engines]
     gro.collect(trajs, logps=lps, values=vas)
@@ -314,6 +314,11 @@ def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deter
             assert np.array_equal(trajs[i].obs[t + 1].cpu().numpy(), oobs) and np.array_equal(trajs[i].reward[t].cpu().numpy(), orew)
     if not deterministic:
         assert len(np.unique(want[0][0].actions.cpu().numpy())) == 6
+    # compact records written by the joint env launch itself (oc_group_step's d_records): every slot re-featurises to its observation
+    from diverse_conventions_amd import TrajectoryExchange
+    for i in (0, 2):
+        assert torch.equal(TrajectoryExchange().featurize_all(engines[i], trajs[i].records.unsqueeze(0)), trajs[i].obs), i
+        assert torch.equal(trajs[i].records[T], engines[i].export_states())
     # in-place stepping continues the draw counter where the collection stopped
     obs, rew, done = gro.step(3)
     assert gro.steps_done == T + 3 and obs[0].data_ptr() == engines[0].obs.data_ptr()
@@ -321,3 +326,48 @@ def test_group_rollout_with_policies_equals_per_engine_rollouts(partition, deter
     grp.close(close_engines=True)
     for tr, _, _ in want:
         tr.engine.close()
+
+
+@pytest.mark.gpu
+def test_group_with_other_player_counts_is_refused_by_the_policy_rollouts(layout_params):
+    """A group may hold engines with 1, 3 or 4 players (its joint step then runs them on the plain kernels), but the fused policy
+    kernel reads 2-player observations and the paired rollouts' action / reward buffers are [2, N]: both C entry points and the
+    Python class refuse such a group instead of reading 30-channel planes as 20-channel rows."""
+    import ctypes
+    from diverse_conventions_amd import EngineGroup, GroupPairedRollout, OvercookedEngine, PackedNetworks, get_base_layout_params, native
+    from diverse_conventions_amd.fused_policy import _shape
+    rng = np.random.default_rng(0)
+    r = lambda *sh: (rng.standard_normal(sh) * 0.1).astype(np.float32)
+    p4 = get_base_layout_params("multiplayer_schelling", 200)
+    two = OvercookedEngine(layout_params["simple"], 96, 0)
+    four = OvercookedEngine(p4, 96, 0)
+    assert four.num_players == 4
+    grp = EngineGroup([two, four])
+    nets = []
+    for W, H in ((5, 4), (p4["width"], p4["height"])):
+        P = (W - 2) * (H - 2)
+        sd = {"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P), "base.cnn.cnn.3.bias": r(64),
+              "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64), "act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)}
+        nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[sd]))
+    with pytest.raises(native.OvercookedNativeError, match="2-player"):
+        GroupPairedRollout(grp, nets, [96, 96], 0)
+    # the C entry points themselves, handed well-formed slots
+    L = native.lib()
+    shapes = [_shape(nt.W, nt.H, 6, nt.digits) for nt in nets]
+    tiles = torch.tensor([[0, 192, 0, 1]], dtype=torch.int32, device="cuda")
+    acts = [torch.zeros((2, 96), dtype=torch.int32, device="cuda") for _ in range(2)]
+    slots = (native.OcGroupPolicySlot * 2)()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    for i, e in enumerate((two, four)):
+        sl = slots[i]
+        sl.shape = ctypes.pointer(shapes[i])
+        sl.d_packed, sl.n_nets, sl.d_tiles, sl.n_tiles = vp(nets[i].image), 1, vp(tiles), 1
+        sl.d_obs, sl.d_actions, sl.d_reward, sl.d_done = vp(e.obs), vp(acts[i]), vp(e.reward), vp(e.done)
+    before = four.export_states().clone()
+    rc = L.oc_group_policy_rollout(grp._handle, slots, 2, 1, 0, 0, 0, None)
+    assert rc == -2 and "2-player" in L.oc_last_error().decode()
+    rc = L.oc_group_policy_rollout_multi(grp._handle, slots, vp(tiles), 1, 1, 4, 2, 1, 0, 0, 0, None)
+    assert rc in (-1, -2) and "2-player" in L.oc_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(four.export_states(), before)              # nothing was stepped
+    grp.close(close_engines=True)

@@ -126,3 +126,43 @@ def test_bench_refuses_two_ranks_on_one_device():
         bench.check_distinct_devices([a, dict(b, device_index=0)])
     assert bench.check_distinct_devices([a, dict(b, device_index=0)], allow_shared=True) == 1
     assert bench.algorithmic_bytes(20) == 1012 and bench.algorithmic_bytes(45) == 2212
+
+
+def test_bench_self_launch_builds_the_drivers_command(monkeypatch):
+    """`python bench.py --gpus N` without a rendezvous in the environment starts torch.distributed.run as a CHILD process with the
+    driver's own arguments and relays its line and exit code; the parent imports neither torch.cuda nor the engine."""
+    import importlib
+    import io
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None, cwd=None):
+            seen.update(cmd=cmd, env=env, cwd=cwd)
+            self.stdout = io.StringIO('noise\n{"metric": "m", "n_gpus": 4}\n')
+
+        def wait(self):
+            return 0
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "3"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    out = io.StringIO()
+    monkeypatch.setattr(sys, "stdout", out)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"]
+    assert seen["env"]["OC_BENCH_LAUNCHER"] == "self" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert out.getvalue().count('{"metric"') == 1
+    # a child that fails: its exit code is the launcher's
+    FakeProc.wait = lambda self: 3
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3

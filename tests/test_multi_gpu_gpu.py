@@ -107,6 +107,18 @@ def test_trajectory_buffer_is_filled_in_place(layout_params):
     assert np.array_equal(buf.actions.cpu().numpy(), acts)
     for t in (0, 77, T):
         assert np.array_equal(eng.encode_states(buf.records[t]).cpu().numpy(), want[t])
+    # the records were written by the step launches themselves (oc_step's d_records): every slot equals the oracle's state after
+    # that many steps, and the compact fields are views of ONE flat buffer in the exchange's wire order
+    from diverse_conventions_amd.engine import pack_states
+    chk = oracle.OracleVecEnv(params, n)
+    recs = buf.records.cpu().numpy()
+    for t in range(T + 1):
+        if t:
+            chk.step(acts[t - 1])
+        assert np.array_equal(recs[t].view(np.uint32), pack_states(*chk.get_state(), eng.record_bytes)), t
+    assert buf.records.data_ptr() == buf.wire.data_ptr() and buf.wire.numel() * 4 == (T + 1) * n * eng.record_bytes + (2 + 2 + 1) * T * n * 4 + 4 * sum(
+        (-w) % 4 for w in (T * 2 * n, T * 2 * n, T * n))
+    assert torch.equal(buf.records[T], eng.export_states())
     with pytest.raises(IndexError):
         buf.step(dacts[0])
     buf.after_update()
@@ -115,6 +127,18 @@ def test_trajectory_buffer_is_filled_in_place(layout_params):
     buf2 = TrajectoryBuffer(eng2, T).rollout(dacts)
     assert np.array_equal(buf2.obs.cpu().numpy(), np.stack(want)) and np.array_equal(buf2.reward.cpu().numpy(), np.stack(rews))
     assert buf2.agent_view(1).shape == (T + 1, n, 5, 4, 20)
+    # the same trajectory, records included, as T launches enqueued by one C call (oc_rollout), as ONE launch (oc_rollout_fused: the
+    # records leave the LDS-resident state once per step), and with a single observation slot overwritten in place
+    for how in ("tape", "fused", "one_slot"):
+        e3 = OvercookedEngine(params, n, 0)
+        b3 = TrajectoryBuffer(e3, T, store_states=True, obs_slots=1 if how == "one_slot" else None)
+        b3.rollout(dacts) if how == "fused" else b3.rollout_tape(dacts)
+        assert torch.equal(b3.wire, buf.wire), how
+        if how == "one_slot":
+            assert b3.obs.shape[0] == 1 and np.array_equal(b3.obs[0].cpu().numpy(), want[T])
+        else:
+            assert torch.equal(b3.obs, buf.obs), how
+        e3.close()
     eng.close(); eng2.close()
 
 

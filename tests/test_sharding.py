@@ -121,3 +121,95 @@ def test_compact_trajectory_all_gather_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: True, 1: True}
+
+
+class _OracleEngine:
+    """What TrajectoryExchange needs of an engine, served by the CPU oracle: geometry + `encode_trajectory_into` with the engine's
+    argument meaning (records [T, n, rec/4] of one peer -> kitchens [offset, offset + n) of every slot of [T, P, N_total, W, H, C])."""
+
+    def __init__(self, params, n):
+        from oracle import oracle
+        self.params, self.num_kitchens, self.num_players = params, n, 2
+        self.width, self.height, self.channels = params["width"], params["height"], 20
+        self.size = self.width * self.height
+        self.record_bytes = 16 * ((self.size + 4 + 3) // 4)
+        self._ora = oracle.OracleVecEnv(params, n)
+
+    def encode_trajectory_into(self, records, obs_global, kitchen_offset):
+        T, n = records.shape[0], records.shape[1]
+        for t in range(T):
+            self._ora.set_state(*unpack_states(records[t].numpy().view(np.uint32), self.size))
+            obs_global[t, :, kitchen_offset:kitchen_offset + n] = torch.from_numpy(self._ora.encode())
+        return obs_global
+
+
+def _worker_world8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from types import SimpleNamespace
+        from conftest import GOLDEN
+        from oracle import oracle
+        from diverse_conventions_amd.trajectory import wire_layout
+        with open(os.path.join(GOLDEN, "layout_params.json")) as f:
+            params = json.load(f)["unident_s"]                      # asymmetric_advantages: config 4's layout
+        total, T = 8 * 6, 9                                          # six kitchens per rank
+        shard = KitchenShard(total, world, rank)
+        n, sl = shard.count, slice(shard.first, shard.first + shard.count)
+        rng = np.random.default_rng(11)
+        acts_all = rng.integers(0, 6, size=(T, 2, total)).astype(np.int32)
+        eng = _OracleEngine(params, n)
+        # this rank's trajectory, laid out exactly as TrajectoryBuffer(store_states=True) lays it out: ONE flat int32 buffer
+        fields, words = wire_layout(T, 2, n, eng.record_bytes // 4)
+        wire = torch.zeros(words, dtype=torch.int32)
+        view = lambda name: wire[fields[name][0]:fields[name][0] + int(np.prod(fields[name][1]))].view(fields[name][1])
+        env = oracle.OracleVecEnv(params, n, nthreads=1)
+        env.timestep[:] = (np.arange(shard.first, shard.first + n) * 37) % 200       # staggered phases: resets inside the trajectory
+        own_obs = [env.encode().copy()]
+        view("records")[0] = torch.from_numpy(pack_states(*env.get_state(), eng.record_bytes).view(np.int32))
+        for t in range(T):
+            o, r, d = env.step(acts_all[t][:, sl])
+            own_obs.append(o.copy())
+            view("records")[t + 1] = torch.from_numpy(pack_states(*env.get_state(), eng.record_bytes).view(np.int32))
+            view("actions")[t] = torch.from_numpy(acts_all[t][:, sl].copy())
+            view("reward")[t] = torch.from_numpy(r)
+            view("done")[t] = torch.from_numpy(d)
+        traj = SimpleNamespace(T=T, P=2, wire=wire, engine=eng)
+        ex = TrajectoryExchange()
+        recv = torch.empty(world * words, dtype=torch.int32)
+        got = ex.gather_buffer(traj, out=recv)
+        ok = ex.collectives == 1 and got["records"].shape == (world, T + 1, n, eng.record_bytes // 4) and got["records"].data_ptr() == recv.data_ptr()
+        ok &= all(got[k][p].data_ptr() % 16 == 0 for k in got for p in range(world))        # every peer's every field 16-byte aligned
+        ok &= all(torch.equal(got[k][rank], view(k)) for k in got)                          # own shard at its own index
+        ok &= bool(torch.equal(torch.cat([got["actions"][p] for p in range(world)], dim=2), torch.from_numpy(acts_all)))
+        # the receive side: all eight peers' shards re-featurised at their kitchen offsets of the global tensor
+        out = ex.featurize_all(eng, got["records"])
+        ok &= out.shape == (T + 1, 2, total, eng.width, eng.height, 20)
+        ok &= bool(np.array_equal(out[:, :, sl].numpy(), np.stack(own_obs)))
+        # ... and every rank holds the same global tensor and the same done / reward columns (checked through a second collective)
+        digest = torch.tensor([int(out.to(torch.int64).sum()), int((out.to(torch.int64) * torch.arange(out.numel()).view(out.shape).remainder(8191)).sum()),
+                               int(got["done"].sum()), int(got["reward"].sum())])
+        all_d = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(all_d, digest)
+        ok &= all(torch.equal(d, digest) for d in all_d) and int(got["done"].sum()) > 0
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wire_buffer_all_gather_gloo_world8():
+    """Eight ranks -- the node the north star names -- on the CPU: every rank's flat wire buffer through ONE all_gather_into_tensor
+    (no concatenation), per-field views at eight peers' offsets, and featurize_all dropping eight shards at their kitchen offsets."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_world8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {r: True for r in range(world)}
