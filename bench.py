@@ -359,6 +359,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
+    # stdout carries the ONE JSON line and nothing else: libraries that print banners there (RCCL's version block on communicator
+    # set-up) are sent to stderr by pointing fd 1 at fd 2 for the life of the process; the line goes out through a copy of the real fd
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
@@ -788,7 +793,7 @@ def main():
             out["config4_share_policy_in_loop"] = share
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, n)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     eng.close()
     if use_dist:
         dist.destroy_process_group()

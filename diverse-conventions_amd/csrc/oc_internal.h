@@ -3,13 +3,29 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+// What the PRODUCT library reads from the environment: OC_NO_JIT (serve the ahead-of-time generic kernels), OC_JIT_CACHE (where
+// compiled code objects are kept), OC_DWORD_STORES (the dword-store kernels for 4-byte-aligned-only consumers' tests) and
+// OC_POLICY_COOP (0: no cooperative blocks, for plan-equality checks; documented f32-rounding effect) -- none of them changes an
+// environment result.  Every experiment / timing knob (store modes, code-generation switches, phase ablation, traces, the folded env
+// step ...) is read through OC_DIAG_ENV, which is getenv only in the diagnostics build (-DOC_DIAGNOSTICS -> csrc/liboc_hip_diag.so,
+// loaded by tools/ through OC_DIAGNOSTICS=1): in the product library the names do not even exist as strings.
+#ifdef OC_DIAGNOSTICS
+#define OC_DIAG_ENV(name) getenv(name)
+#else
+#define OC_DIAG_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 int oc_internal_fail(int code, const char *fmt, ...);      // overcooked_engine.hip: sets oc_last_error()
 struct oc_group;
 struct oc_engine;
 oc_engine *oc_internal_group_engine(oc_group *g, int i);    // overcooked_engine.hip: engine i of a group (NULL if out of range)
 int oc_internal_set_cu_budget(oc_engine *e, int cus);        // size the engine's launches for a CU-masked stream (0 = whole device)
 
-// ---- the env step folded into the policy launch (policy_ops.hip: oc_policy_rollout, "one launch per training step") ----------
+#ifdef OC_DIAGNOSTICS
+// ---- the env step folded into the policy launch (policy_ops.hip: oc_policy_rollout, "one launch per training step"): built, bit-exact,
+// measured 2x slower than two launches -- kept for tools/exp_fold_ab.py in the diagnostics build only ----------
 // A fold group is kFoldKitchens consecutive kitchens, stepped inside the policy kernel by the wavefront whose block completed
 // the group's actions, as kFoldKitchens / kFoldKpw sub-groups of the generic step body (oc_step_kernel.h).
 namespace oc_dev { struct StepArgs; }
@@ -24,6 +40,7 @@ int oc_internal_fold_args(oc_engine *e, const void *d_actions, int8_t *d_obs, in
 // kernel's env call takes that template by pointer and the per-step pointers by value, which keeps a 250-byte struct out of its
 // call frames.
 int oc_internal_fold_workspace(oc_engine *e, int32_t **d_count, int32_t **d_expected, int32_t *n_groups, const oc_dev::StepArgs **d_args_template);
+#endif  // OC_DIAGNOSTICS
 void oc_internal_note_destination(oc_engine *e, const int8_t *d_obs);   // the engine's "previous destination" (store mode choice of oc_step)
 // Rollouts with the policies in the loop: the planes a step writes into a fresh (time-major) slot are read by the very next launch, the
 // policy kernel.  While the flag is set such steps store them plainly -- they stay in L2 for that launch, and their write-back hides

@@ -69,8 +69,15 @@ namespace oc_dev {
 #define KP_start_posor(a) ((a).start_posor)
 #define KP_delta_pack(a) ((a).delta_pack)
 #define KP_n_kitchens(a) ((a).n_kitchens)
+// phase ablation and the per-wave phase stamps exist in the diagnostics build only (-DOC_DIAGNOSTICS: csrc/liboc_hip_diag.so, tools/):
+// the product library's kernels have neither the branches nor a way to switch them on
+#ifdef OC_DIAGNOSTICS
 #define KP_ablate(a) ((a).ablate)
 #define KP_trace(a) ((a).trace)
+#else
+#define KP_ablate(a) (0)
+#define KP_trace(a) (static_cast<unsigned long long *>(nullptr))
+#endif
 #define KP_pots4(a, i) ((a).pots4[i])
 #endif
 
@@ -185,8 +192,8 @@ struct StepArgs {
     // aligned), step t of a FUSED rollout to rec_out + t * rec_step_stride; NULL = not recorded
     uint4 *rec_out;
     int64_t rec_step_stride;    // uint4 between consecutive steps' record blocks (FUSED kernels only)
-    int32_t ablate;             // timing diagnostics only (env OC_ABLATE at oc_create); 0 in production
-    unsigned long long *trace;  // timing diagnostics only: [wave][8] s_memrealtime stamps (100 MHz), else NULL
+    int32_t ablate;             // diagnostics build only (tools/ablate.py): phases to skip; always 0 in the product library
+    unsigned long long *trace;  // diagnostics build only: [wave][8] s_memrealtime stamps (100 MHz); always NULL in the product library
 };
 
 // One launch over several engines (oc_group_step / oc_group_observe): blocks [first_block[s], first_block[s+1]) of the

@@ -6,8 +6,8 @@
 // No include guard; everything it names is a local of the kernel.
         constexpr bool cp = OC_BLOCK_COOP != 0;
         const long long brow = row0 + static_cast<long long>(blk) * kRowsPerBlock;
-        const bool traced = a.trace != nullptr && !trace_done;       // diagnostics: this wavefront's first block of the launch
-        const bool traced2 = a.trace != nullptr && trace_done && !trace2_done;   // ... and, finer, its second
+        const bool traced = kPolicyTrace && a.trace != nullptr && !trace_done;       // diagnostics build: this wavefront's first block of the launch
+        const bool traced2 = kPolicyTrace && a.trace != nullptr && trace_done && !trace2_done;   // ... and, finer, its second
         if (trace_done) trace2_done = true;
         trace_done = true;
         if (traced2) stamp(a, wave, lane, 16);

@@ -50,7 +50,9 @@
 #include "overcooked_debug.h"
 #include "oc_internal.h"
 #include "policy_pack.h"
-#include "oc_step_kernel.h"     // the generic env step body: folded into the policy launch (FOLD builds)
+#ifdef OC_DIAGNOSTICS
+#include "oc_step_kernel.h"     // the generic env step body: folded into the policy launch (FOLD builds, diagnostics only)
+#endif
 
 
 namespace {
@@ -63,7 +65,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
-constexpr bool kFoldByDefault = false;   // oc_policy_rollout: env step folded into the policy launch unless OC_POLICY_FOLD says otherwise
+#ifdef OC_DIAGNOSTICS
+constexpr bool kFoldByDefault = false;   // oc_policy_rollout: two launches per step unless OC_POLICY_FOLD=1 asks for the env step inside the policy launch
+#endif
 constexpr int kMaxOut = 8;
 #ifndef OC_POLICY_LATE_ROWS
 #define OC_POLICY_LATE_ROWS 1
@@ -110,7 +114,8 @@ struct PolicyArgs {
     int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
-    // FOLD builds: the env step of slot 0's engine runs inside this launch (see fold_* below)
+#ifdef OC_DIAGNOSTICS
+    // FOLD builds (diagnostics library only): the env step of slot 0's engine runs inside this launch (see fold_* below)
     const oc_dev::StepArgs *fold_args;  // device copy of the engine's step arguments, fold geometry, without the per-step pointers ...
     const void *fold_actions;           // ... which are these: the action buffer this launch fills, and the step's outputs
     int8_t *fold_obs;
@@ -120,10 +125,17 @@ struct PolicyArgs {
     const int32_t *fold_expected;       // [fold_groups] actor blocks that touch the group (fold_expected_kernel)
     int fold_groups;                    // ceil(N / kFoldKitchens)
     int fold_nt;                        // the env step's plane stores: 0 write-through (in place), 1 write-through non-temporal (fresh slot)
+#endif
 };
 
+// (phase stamps exist in the diagnostics build only; in the product library the calls compile to nothing)
+#ifdef OC_DIAGNOSTICS
+constexpr bool kPolicyTrace = true;
+#else
+constexpr bool kPolicyTrace = false;
+#endif
 __device__ __forceinline__ void stamp(const PolicyArgs &a, int wave, int lane, int slot) {
-    if (a.trace && lane == 0)
+    if (kPolicyTrace && a.trace && lane == 0)
         a.trace[(static_cast<size_t>(blockIdx.x) * 8 + wave) * 32 + slot] = (slot == 14 || slot == 15) ? clock64() : wall_clock64();
 }
 
@@ -446,7 +458,9 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
     return true;
 }
 
-// ---- the env step inside the policy launch ("one launch per training step") -------------------------------------------------
+#ifdef OC_DIAGNOSTICS
+// ---- the env step inside the policy launch ("one launch per training step"; diagnostics build only: measured 2x slower than two
+// launches) -------------------------------------------------
 // The reference's loop is policy -> env -> policy (train/XD/xd_player.py:178-230); as two launches per step the env launch is a
 // kernel of its own that the matrix pipe waits out.  FOLD builds run it inside the policy launch, overlapped with other
 // wavefronts' MFMA work: kitchens are cut into fold groups of kFoldKitchens; every actor block, once its actions are stored and
@@ -522,6 +536,7 @@ __device__ __attribute__((noinline)) void fold_env_group(const oc_dev::StepArgs 
     else oc_dev::generic::step_body<true, false, true, kFoldQN, oc_dev::SM_SC1, false, false, true>(ea, g * kSub, 1, lds, lane);
     if (lane == 0) count[g] = 0;                                      // every contributor has arrived: ready for the next launch
 }
+#endif  // OC_DIAGNOSTICS
 
 // MULTI: the tile table runs over several slots (grids); everything that depends on the grid is then re-derived per tile.
 // Such launches keep the conv digits in registers and fc1 in L2 (the LDS-resident tail -- biases, fc2, head -- has the same
@@ -661,6 +676,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     int fold_g = 0, fold_old = 0, fold_exp = 0, fold_n = 0;
     long long fold_r0 = 0, fold_r1 = -1;                              // rows of the last actor block whose arrival is still to be announced
     auto fold_drain = [&]() {                                         // call only where this wavefront's staging area is free
+#ifdef OC_DIAGNOSTICS
         if (!FOLD || fold_n == 0) return;
         unsigned long long mine = __ballot(lane < fold_n && fold_old + 1 == fold_exp);
         fold_n = 0;
@@ -678,8 +694,10 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                                static_cast<int>((ldsw - lds) >> 2), lane, a.fold_count);
         }
         wave_lds_sync();
+#endif
     };
     auto fold_arrive = [&](long long r0, long long r1) {              // after a block's actions are stored
+#ifdef OC_DIAGNOSTICS
         if (!FOLD) return;
         int g[4];
         const int n = fold_block_groups(r0, r1, a.fold_kitchens, g);
@@ -690,7 +708,11 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
             fold_old = atomicAdd(a.fold_count + mine, 1);
         }
         fold_n = n;
+#else
+        (void)r0; (void)r1;
+#endif
     };
+    (void)fold_g; (void)fold_old; (void)fold_exp; (void)fold_n;
 
   for (long long cur = wg0; cur < wg1;) {
     // (read the way policy_find_stretch read it -- scalar for tables mapped to workgroups, vector for a table split evenly -- so that it hits the cache
@@ -848,6 +870,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         }
     }
   }
+#ifdef OC_DIAGNOSTICS
     if (FOLD) {
         fold_drain();                                                 // requests of the last block but one
         if (fold_r1 >= 0) {                                           // the last block: its actions (agent-scope stores, written through) must have completed
@@ -863,6 +886,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
                 wave_lds_sync();
             }
     }
+#endif
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
@@ -873,8 +897,10 @@ __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, u
         dst[i] = oc_policy_pack_word(L, w, i);
 }
 
-unsigned long long *g_trace = nullptr;    // device buffer of the diagnostics entry below
+unsigned long long *g_trace = nullptr;    // device buffer of the diagnostics entry below (stays NULL in the product library)
+#ifdef OC_DIAGNOSTICS
 long long g_fold_launches = 0;            // policy launches that carried the env step (oc_debug_fold_launches)
+#endif
 
 int check_shape(const oc_policy_shape *s, const char *who) {
     if (!s) return oc_internal_fail(OC_ERR_INVALID_ARG, "%s: shape is NULL", who);
@@ -1038,6 +1064,9 @@ int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_r
     // At least two workgroups per segment: the single-grid plan with costs -- workgroups shared out over the segments in proportion
     // to their work, one tile each, no workgroup ever changes network (config 3's actors: 96 us per joint step against 103 packed).
     // With fewer, whole workgroups per segment no longer balance (235 segments on 256 workgroups: 196 us against 155 packed).
+    const int32_t waves_hint = *waves_per_workgroup;                  // in: 0 = choose, 1 = wave tiles, 4 = four-wavefront workgroups
+    if (waves_hint != 0 && waves_hint != 1 && waves_hint != 4)
+        return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_plan_tiles_multi: *waves_per_workgroup is 0 (choose), 1 or 4 on entry");
     *waves_per_workgroup = 4;
     {
         int32_t live = 0;
@@ -1048,8 +1077,7 @@ int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_r
         }
         // Short segments (fewer than kWaveTileBlocks 32-row blocks each, on average): wave tiles -- four one-wavefront workgroups
         // per CU, each with its own network in L2 / registers, planned as 4 x workgroups packed stretches.
-        const char *const env_wt = getenv("OC_POLICY_WAVE_TILES");   // diagnostics: "0" never, "1" always
-        const bool wave_tiles = env_wt && env_wt[0] ? env_wt[0] != '0' : (live > 0 && all_blocks < static_cast<int64_t>(kWaveTileBlocks) * live);
+        const bool wave_tiles = waves_hint ? waves_hint == 1 : (live > 0 && all_blocks < static_cast<int64_t>(kWaveTileBlocks) * live);
         if (wave_tiles) {
             *waves_per_workgroup = 1;
             workgroups *= 4;
@@ -1194,7 +1222,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     // role split'; profiles/r02_policy_pair_split.log, r02_policy_conv_dense_split.log).  tools/probes/coexec.hip shows why:
     // on one gfx950 SIMD a partner wavefront's VALU work does not overlap back-to-back MFMAs of any type (both together cost
     // the sum, not the maximum), so a second wavefront per SIMD can only fill MFMA-free gaps, not hide work.
-    const char *const env_plan = getenv("OC_POLICY_PLAN");           // diagnostics: "waves,fc1_lds,conv_lds" (read per call)
+    const char *const env_plan = OC_DIAG_ENV("OC_POLICY_PLAN");           // diagnostics: "waves,fc1_lds,conv_lds" (read per call)
     if (env_plan && env_plan[0] && !multi) {
         int w = 0, f = 0, c = 0;
         if (sscanf(env_plan, "%d,%d,%d", &w, &f, &c) == 3 && w >= 1 && w <= 8) { waves = w; fc1_lds = f != 0; conv_lds = c != 0; }
@@ -1223,16 +1251,23 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
                                                      {{OC_PK(3, false, false), OC_PK(3, false, true)}, {OC_PK(3, true, false), OC_PK(3, true, true)}},
                                                      {{OC_PK(4, false, false), OC_PK(4, false, true)}, {OC_PK(4, true, false), OC_PK(4, true, true)}}};
 #undef OC_PK
+#ifdef OC_DIAGNOSTICS
 #define OC_PK(F, C) oc_policy_kernel<3, F, C, false, true, false, true>
     static const kernel_t kernels_fold[2][2] = {{OC_PK(false, false), OC_PK(false, true)}, {OC_PK(true, false), OC_PK(true, true)}};   // (3 digits: the default)
 #undef OC_PK
     const bool fold = a.fold_count != nullptr;
     if (fold && (multi || wave_tiles || digits != 3 || s0.row_index))
         return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: the folded env step needs a single-grid launch of 3-digit networks");
+#else
+    const bool fold = false;                                          // (no FOLD instantiation exists in the product library)
+#endif
     const bool gather = !multi && s0.row_index != nullptr;
-    const kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1]
-                          : gather ? kernels_gather[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0]
-                          : fold ? kernels_fold[fc1_lds ? 1 : 0][conv_lds ? 1 : 0] : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+    kernel_t kernel = wave_tiles ? kernels_wave[digits - 1] : multi ? kernels_multi[digits - 1]
+                      : gather ? kernels_gather[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0]
+                      : kernels[digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+#ifdef OC_DIAGNOSTICS
+    if (fold && !wave_tiles && !multi && !gather) kernel = kernels_fold[fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
+#endif
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
@@ -1262,12 +1297,12 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     // (more tiles than CUs -- many segments on a small CU share -- would need a second round of workgroups: split evenly instead)
     // Several grids: workgroup i owns tile_per_wg consecutive entries of the table (oc_policy_plan_tiles_multi).
     if (!multi) a.tile_per_wg = (a.n_tiles >= n_cus / 2 && a.n_tiles <= n_cus) ? 1 : 0;
-    static const char *const env_desync = getenv("OC_POLICY_DESYNC");
+    static const char *const env_desync = OC_DIAG_ENV("OC_POLICY_DESYNC");
     a.desync = env_desync ? atoi(env_desync) : 0;
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
     a.coop = env_coop ? atoi(env_coop) != 0 : 1;
     int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
-    static const char *const env_grid = getenv("OC_POLICY_GRID");
+    static const char *const env_grid = OC_DIAG_ENV("OC_POLICY_GRID");
     if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, stream, a);
     const hipError_t err = hipGetLastError();
@@ -1292,7 +1327,8 @@ struct PlanesReadNext {
     PlanesReadNext &operator=(const PlanesReadNext &) = delete;
 };
 
-// the env step folded into the launch (oc_policy_rollout): the engine's step arguments for this step and the fold groups' counters
+// the env step folded into the launch (oc_policy_rollout, diagnostics build): the engine's step arguments for this step and the fold groups' counters
+#ifdef OC_DIAGNOSTICS
 struct FoldParams {
     const oc_dev::StepArgs *args;       // device template (oc_internal_fold_workspace)
     const void *actions;
@@ -1304,6 +1340,9 @@ struct FoldParams {
     int groups, nt;
     size_t lds_need;
 };
+#else
+struct FoldParams;                      // (never instantiated in the product library)
+#endif
 
 static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                                const int32_t *d_tiles, int32_t n_tiles, const int32_t *d_row_index, const int32_t *d_row_count, int64_t gather_len,
@@ -1324,6 +1363,7 @@ static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packe
     a.tiles = reinterpret_cast<const int4 *>(d_tiles);
     a.n_tiles = n_tiles;
     a.counter = counter; a.counter_ptr = d_counter; a.sample = sample_mode;
+#ifdef OC_DIAGNOSTICS
     if (fold) {
         a.fold_args = fold->args; a.fold_actions = fold->actions; a.fold_obs = fold->obs; a.fold_reward = fold->reward; a.fold_done = fold->done;
         a.fold_kitchens = fold->kitchens;
@@ -1331,6 +1371,9 @@ static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packe
         if (static_cast<size_t>(staging_bytes(a.slot[0].RB)) < fold->lds_need)
             return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: the env step's LDS block does not fit a row-staging area");
     }
+#else
+    (void)fold;
+#endif
     return launch_policy(a, shape->digits, false, cu_budget, static_cast<hipStream_t>(stream));
 }
 
@@ -1395,12 +1438,13 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
     const int64_t n = shp[1], rows = 2 * n, slot = rows * shp[2] * shp[3] * shp[4], rec_slot = n * oc_state_record_bytes(e);
     const OcDeviceScope on_device(oc_device_id(e));       // once for the whole rollout; the per-step calls then find it current
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: cannot make device %d current", oc_device_id(e));
-    // ONE launch per step: the env step folded into the policy launch (see fold_* above) wherever the shapes allow it -- 3-digit
-    // networks, no per-row selection, records and LDS block within the fold's windows.  OC_POLICY_FOLD=0 keeps the two launches.
-    FoldParams fp;
+    // Two launches per step.  (ONE launch per step -- the env step folded into the policy launch, see fold_* above -- was built, is
+    // bit-exact and measured 2x slower, DESIGN.md 9b: the diagnostics build keeps it behind OC_POLICY_FOLD=1 for tools/exp_fold_ab.py.)
     bool fold = false;
+#ifdef OC_DIAGNOSTICS
+    FoldParams fp;
     {
-        const char *env_fold = getenv("OC_POLICY_FOLD");
+        const char *env_fold = OC_DIAG_ENV("OC_POLICY_FOLD");
         const bool want = env_fold ? (env_fold[0] && env_fold[0] != '0') : kFoldByDefault;
         int32_t *cnt = nullptr, *expd = nullptr, groups = 0;
         const oc_dev::StepArgs *tmpl = nullptr;
@@ -1418,15 +1462,17 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
             if (hipGetLastError() != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_rollout: fold_expected_kernel launch failed");
             fp.args = tmpl; fp.kitchens = n;
             fp.count = cnt; fp.expected = expd; fp.groups = groups; fp.nt = in_place ? 0 : 1;
-            if (const char *dbg = getenv("OC_FOLD_DEBUG")) fp.nt |= atoi(dbg) & ~1;      // timing diagnostics only (results then wrong by design)
+            if (const char *dbg = OC_DIAG_ENV("OC_FOLD_DEBUG")) fp.nt |= atoi(dbg) & ~1;      // timing diagnostics only (results then wrong by design)
             fold = true;
         }
     }
+#endif
     const PlanesReadNext hint(e);                                     // (every step's planes are the next policy launch's input)
     for (int64_t t = 0; t < T; ++t) {
         const int64_t k = in_place ? 0 : t;
         int8_t *obs_t = d_obs + k * slot, *obs_next = in_place ? d_obs : d_obs + (t + 1) * slot;
         int32_t *act_t = d_actions + k * rows;
+#ifdef OC_DIAGNOSTICS
         if (fold) {
             fp.actions = act_t; fp.obs = obs_next; fp.reward = d_reward + k * rows; fp.done = d_done + k * n;
             if (int rc = policy_forward_impl(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, nullptr, nullptr, 0, d_values ? d_values + k * rows : nullptr,
@@ -1437,6 +1483,7 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
             ++g_fold_launches;
             continue;
         }
+#endif
         if (int rc = oc_policy_forward(shape, d_packed, n_nets, obs_t, rows, d_tiles, n_tiles, d_values ? d_values + k * rows : nullptr, act_t,
                                        d_action_logp ? d_action_logp + k * rows : nullptr, nullptr, sample_mode, seed,
                                        counter0 + static_cast<uint32_t>(t), nullptr, d_row_select ? d_row_select + t * rows : nullptr, stream))
@@ -1687,7 +1734,8 @@ int oc_group_policy_rollout_multi(oc_group *g, const oc_group_policy_slot *slots
     return OC_OK;
 }
 
-/* Diagnostics (overcooked_debug.h): per-wavefront phase stamps of the following launches
+#ifdef OC_DIAGNOSTICS
+/* Diagnostics build (overcooked_debug.h): per-wavefront phase stamps of the following launches
  * (tools/trace_policy.py).  enable: allocate and zero; otherwise copy [n_waves][16] stamps out and free. */
 int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_waves) {
     const size_t cap = 4096 * 4 * 32 * sizeof(unsigned long long);
@@ -1704,6 +1752,7 @@ int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_wa
 }
 
 long long oc_debug_fold_launches(void) { return g_fold_launches; }
+#endif  // OC_DIAGNOSTICS
 
 float oc_policy_uniform(uint32_t seed, uint32_t counter, uint32_t row, uint32_t action) {
     return oc_policy_uniform_from_hash(oc_policy_hash(seed, counter, row, action));

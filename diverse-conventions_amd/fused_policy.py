@@ -213,7 +213,10 @@ class MultiPolicyPlan:
 
     nets[i]: PackedNetworks of grid i; n_rows[i]; segments[i]: (row0, rows, net, flags) inside grid i."""
 
-    def __init__(self, nets: Sequence[PackedNetworks], n_rows: Sequence[int], segments, workgroups: Optional[int] = None):
+    def __init__(self, nets: Sequence[PackedNetworks], n_rows: Sequence[int], segments, workgroups: Optional[int] = None,
+                 waves_per_workgroup: int = 0):
+        """waves_per_workgroup: 0 lets the planner choose (wave tiles for tables of short segments), 1 forces one-wavefront workgroups
+        ("wave tiles"), 4 four-wavefront workgroups."""
         self.nets, self.n_rows = list(nets), [int(n) for n in n_rows]
         if not 1 <= len(self.nets) <= 8 or len(self.n_rows) != len(self.nets) or len(segments) != len(self.nets):
             raise ValueError("1..8 grids, with one row count and one segment list each")
@@ -236,11 +239,12 @@ class MultiPolicyPlan:
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         L = native.lib()
         args = [p(c) for c in cols] + [p(cost), len(self.nets), len(seg), self.workgroups]
-        per, waves = ctypes.c_int32(0), ctypes.c_int32(0)
+        per, waves = ctypes.c_int32(0), ctypes.c_int32(int(waves_per_workgroup))
         n = L.oc_policy_plan_tiles_multi(*args, None, 0, ctypes.byref(per), ctypes.byref(waves))
         if n < 0:
             native.check(int(n))
         tiles = np.zeros((max(int(n), 1), 4), dtype=np.int32)
+        waves = ctypes.c_int32(int(waves_per_workgroup))
         n2 = L.oc_policy_plan_tiles_multi(*args, p(tiles), int(n), ctypes.byref(per), ctypes.byref(waves))
         if n2 < 0:
             native.check(int(n2))

@@ -15,10 +15,14 @@ CSRC = os.path.join(_HERE, "csrc")
 #   OC_SANITIZE=1 LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 \
 #       python -m pytest tests -m "not gpu" -k "abi or plan or planner or jit"          (tools/run_sanitized.sh)
 SANITIZE = os.environ.get("OC_SANITIZE", "0") not in ("", "0")
+# OC_DIAGNOSTICS=1: the DIAGNOSTICS build (-DOC_DIAGNOSTICS -> csrc/liboc_hip_diag.so): phase stamps, phase ablation, the folded env
+# step and every experiment knob read from the environment (OC_STORE_MODE, OC_POLICY_PLAN, OC_POLICY_FOLD ...).  tools/ set it
+# before importing the package; the product library has none of that code and reads none of those variables.
+DIAGNOSTICS = os.environ.get("OC_DIAGNOSTICS", "0") not in ("", "0")
 # OC_LIB_PATH=<file>: load that build of the library instead (A/B measurements of two builds in one GPU call, tools/ab_builds.sh);
 # build() then leaves it alone
 LIB_OVERRIDE = os.environ.get("OC_LIB_PATH", "")
-LIB_PATH = LIB_OVERRIDE or os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip.so")
+LIB_PATH = LIB_OVERRIDE or os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip_diag.so" if DIAGNOSTICS else "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
 HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h"), os.path.join(CSRC, "policy_block_body.h")]
@@ -58,7 +62,8 @@ SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
 # include/overcooked_experiments.h (measured and not adopted; tools/ only) and include/overcooked_debug.h (diagnostics)
 SYMBOLS_EXPERIMENTS = ["oc_exp_cu_partition_create", "oc_exp_cu_partition_destroy", "oc_exp_policy_forward_cus", "oc_exp_set_cu_budget",
                        "oc_exp_group_policy_rollout_streams"]
-SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group", "oc_debug_trace", "oc_policy_debug_trace", "oc_debug_fold_launches"]
+SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group"]
+SYMBOLS_DIAG = ["oc_debug_trace", "oc_policy_debug_trace", "oc_debug_fold_launches"]       # exported by the diagnostics build only
 
 
 class OcPolicyShape(ctypes.Structure):
@@ -123,23 +128,34 @@ def build(force=False, verbose=False):
     # -amdgpu-mfma-vgpr-form: MFMA results stay in ordinary VGPRs (policy_ops.hip reads them with VALU ops; the
     # accumulator-file form cost 64 v_accvgpr_read per conv position and kept the kernel at one wavefront per SIMD)
     opt = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-shared-libsan"] if SANITIZE else ["-O3"]
+    if DIAGNOSTICS:
+        opt = opt + ["-DOC_DIAGNOSTICS"]
     common = ["hipcc", "--offload-arch=gfx950"] + opt + ["-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-I", INCLUDE]
-    # the three translation units side by side (policy_ops.hip alone is two thirds of the time), then one link
-    objdir = os.path.join(REPO_ROOT, "build", "obj_asan" if SANITIZE else "obj")
-    os.makedirs(objdir, exist_ok=True)
-    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in SOURCES]
-    cmds = [common + ["-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
-    if verbose:
-        for c in cmds:
-            print(" ".join(c))
-    procs = [subprocess.Popen(c) for c in cmds]
-    failed = [c for c, pr in zip(cmds, procs) if pr.wait() != 0]
-    if failed:
-        raise subprocess.CalledProcessError(1, failed[0])
-    link = ["hipcc", "--offload-arch=gfx950"] + (["-fsanitize=address,undefined", "-shared-libsan"] if SANITIZE else []) + ["-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lhiprtc"]
-    if verbose:
-        print(" ".join(link))
-    subprocess.run(link, check=True)
+    # the three translation units side by side (policy_ops.hip alone is two thirds of the time), then one link.  Objects go to a
+    # directory of this process's own and the library is renamed into place whole: two builds running side by side (pytest-xdist, an
+    # A/B of two checkouts sharing build/) can neither clobber each other's objects nor expose a half-written .so
+    import shutil
+    import tempfile
+    os.makedirs(os.path.join(REPO_ROOT, "build"), exist_ok=True)
+    objdir = tempfile.mkdtemp(prefix="obj_asan." if SANITIZE else "obj_diag." if DIAGNOSTICS else "obj.", dir=os.path.join(REPO_ROOT, "build"))
+    try:
+        objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in SOURCES]
+        cmds = [common + ["-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
+        if verbose:
+            for c in cmds:
+                print(" ".join(c))
+        procs = [subprocess.Popen(c) for c in cmds]
+        failed = [c for c, pr in zip(cmds, procs) if pr.wait() != 0]
+        if failed:
+            raise subprocess.CalledProcessError(1, failed[0])
+        tmp_lib = os.path.join(objdir, os.path.basename(LIB_PATH))
+        link = ["hipcc", "--offload-arch=gfx950"] + (["-fsanitize=address,undefined", "-shared-libsan"] if SANITIZE else []) + ["-shared", "-fPIC", "-o", tmp_lib] + objs + ["-lhiprtc"]
+        if verbose:
+            print(" ".join(link))
+        subprocess.run(link, check=True)
+        os.replace(tmp_lib, LIB_PATH)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return LIB_PATH
 
 
@@ -214,10 +230,11 @@ def lib():
     L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), i64, i32, i32, u32, u32, vp]
     L.oc_exp_group_policy_rollout_streams.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
                                                       u32, u32, vp]
-    L.oc_debug_trace.argtypes = [vp, i32, vp, i64]
-    L.oc_policy_debug_trace.argtypes = [i32, vp, i64]
-    L.oc_debug_fold_launches.argtypes = []
-    L.oc_debug_fold_launches.restype = ctypes.c_longlong
+    if DIAGNOSTICS:
+        L.oc_debug_trace.argtypes = [vp, i32, vp, i64]
+        L.oc_policy_debug_trace.argtypes = [i32, vp, i64]
+        L.oc_debug_fold_launches.argtypes = []
+        L.oc_debug_fold_launches.restype = ctypes.c_longlong
     L.oc_group_policy_rollout_multi.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), vp, i32, i32, i32, i64, i32, i32, u32, u32, vp]
     L.oc_policy_forward_multi.argtypes = [ctypes.POINTER(OcPolicyMultiSlot), i32, vp, i32, i32, i32, i32, u32, vp, vp]
     L.oc_policy_plan_tiles_multi.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -245,7 +262,7 @@ def lib():
     L.oc_group_build_info.restype = ctypes.c_char_p
     L.oc_debug_jit_compile_group.argtypes = [ctypes.POINTER(OcLayoutParams), ctypes.POINTER(i64), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, i64]
-    for name in SYMBOLS + SYMBOLS_EXPERIMENTS + SYMBOLS_DEBUG:
+    for name in SYMBOLS + SYMBOLS_EXPERIMENTS + SYMBOLS_DEBUG + (SYMBOLS_DIAG if DIAGNOSTICS else []):
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:          # default restype: int status
             fn.restype = ctypes.c_int

@@ -1,6 +1,10 @@
 /*
- * overcooked_debug.h -- diagnostics exported by the library for the CPU test-suite and the profiling tools; not part of the
- * drop-in boundary.
+ * overcooked_debug.h -- diagnostics; not part of the drop-in boundary.  Two kinds:
+ *   - the compile-only checks of the hiprtc kernel builds: in every build of the library (CPU test-suite, __graft_entry__.build());
+ *   - timing diagnostics (phase stamps, the folded env step's counter): ONLY in the diagnostics build, -DOC_DIAGNOSTICS ->
+ *     csrc/liboc_hip_diag.so, which tools/ load with OC_DIAGNOSTICS=1.  That build also reads the experiment knobs (OC_ABLATE,
+ *     OC_STORE_MODE, OC_POLICY_FOLD ...) from the environment; the product library liboc_hip.so contains neither these entry
+ *     points nor the code behind the knobs, and reads none of them.
  */
 #ifndef OVERCOOKED_DEBUG_H
 #define OVERCOOKED_DEBUG_H
@@ -18,6 +22,7 @@ int oc_debug_jit_compile(const oc_layout_params *p, int64_t n_kitchens, const ch
  * plan_out (optional, 2 * n_engines ints): kitchens per wavefront group and blocks of every engine. */
 int oc_debug_jit_compile_group(const oc_layout_params *params, const int64_t *n_kitchens, int32_t n_engines, int32_t num_cus, const char *arch,
                                int64_t *code_bytes, int32_t *plan_out, char *log_out, int64_t log_cap);
+#ifdef OC_DIAGNOSTICS
 /* Per-wavefront phase stamps (s_memrealtime) of the step kernel's next launches (tools/trace_phases.py).  enable != 0: allocate
  * and zero the trace buffer; 0: copy [max_waves][16] stamps to host_out (may be NULL) and free it. */
 int oc_debug_trace(oc_engine *e, int enable, unsigned long long *host_out, int64_t max_waves);
@@ -26,6 +31,7 @@ int oc_policy_debug_trace(int enable, unsigned long long *host_out, int64_t n_wa
 /* Policy launches so far (this process) that carried the env step inside them (oc_policy_rollout's one-launch-per-step mode): lets a
  * test tell the folded path from its two-launch fallback. */
 long long oc_debug_fold_launches(void);
+#endif /* OC_DIAGNOSTICS */
 
 #ifdef __cplusplus
 }

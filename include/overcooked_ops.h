@@ -155,7 +155,8 @@ int oc_policy_forward_gather(const oc_policy_shape *shape, const void *d_packed,
  * without a block; one balanced table does not.  All slots' networks must use the same number of conv digits; at most 8 slots.
  * *waves_per_workgroup comes back 4, or 1 for tables of short segments (fewer than 12 blocks each on average: "wave tiles" -- the
  * table is then planned for 4 x workgroups one-wavefront workgroups that keep their whole network in L2 / registers, so four
- * different networks run on a CU side by side); pass both numbers on to oc_policy_forward_multi. */
+ * different networks run on a CU side by side); pass both numbers on to oc_policy_forward_multi.  On ENTRY *waves_per_workgroup is
+ * 0 (let the planner choose), 1 or 4 (the caller's choice; results are the same up to the f32 rounding of cooperative blocks). */
 #define OC_POLICY_TILE_SLOT(i) (((i) & 7) << 16)
 typedef struct {
     const oc_policy_shape *shape;

@@ -10,10 +10,13 @@ from conftest import ROOT
 from diverse_conventions_amd import get_base_layout_params, layout_names, native
 
 
-def header_functions(name):
+def header_functions(name, diagnostics=False):
+    """Functions a header declares; `diagnostics`: only those inside its #ifdef OC_DIAGNOSTICS block (else: only those outside)."""
     text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(oc_[a-z_0-9]+)\s*\(", text)))
+    inside = "".join(re.findall(r"#ifdef OC_DIAGNOSTICS\n(.*?)#endif", text, flags=re.S))
+    outside = re.sub(r"#ifdef OC_DIAGNOSTICS\n.*?#endif", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oc_[a-z_0-9]+)\s*\(", inside if diagnostics else outside)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(native.SYMBOLS_OPS) == header_functions("overcooked_ops.h")
     assert sorted(native.SYMBOLS_EXPERIMENTS) == header_functions("overcooked_experiments.h")
     assert sorted(native.SYMBOLS_DEBUG) == header_functions("overcooked_debug.h")
-    declared = native.SYMBOLS + native.SYMBOLS_EXPERIMENTS + native.SYMBOLS_DEBUG
+    assert sorted(native.SYMBOLS_DIAG) == header_functions("overcooked_debug.h", diagnostics=True)
+    declared = native.SYMBOLS + native.SYMBOLS_EXPERIMENTS + native.SYMBOLS_DEBUG + (native.SYMBOLS_DIAG if native.DIAGNOSTICS else [])
     for name in declared:
         assert getattr(L, name) is not None, name
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
@@ -35,6 +39,23 @@ def test_library_exports_every_declared_symbol():
     assert L.oc_abi_version() == 6
     # the drop-in boundary stays small: no experiment or diagnostic leaks into the two public headers
     assert not [f for f in native.SYMBOLS if f.startswith(("oc_exp_", "oc_debug_")) or "_cus" in f or "cu_" in f]
+
+
+def test_product_library_carries_no_diagnostics():
+    """Result-changing timing knobs (phase ablation, the folded env step's debug modes) and lost experiments are compiled out of the
+    shipped library: their environment variables do not exist in it even as strings, the phase-stamp / fold entry points are not
+    exported, and no FOLD instantiation of the policy kernel is in its code objects.  (tools/ build and load csrc/liboc_hip_diag.so.)"""
+    import subprocess
+    if native.DIAGNOSTICS or native.SANITIZE or native.LIB_OVERRIDE:
+        pytest.skip("not the product build")
+    blob = open(native.LIB_PATH, "rb").read()
+    for needle in (b"OC_ABLATE", b"OC_FOLD", b"OC_POLICY_FOLD", b"OC_STORE_MODE", b"OC_POLICY_PLAN", b"OC_JIT_TRACE", b"OC_MIN_WAVES", b"fold_env_group",
+                   b"fold_expected_kernel"):
+        assert needle not in blob, needle
+    for kept in (b"OC_NO_JIT", b"OC_JIT_CACHE", b"OC_DWORD_STORES", b"OC_POLICY_COOP"):      # the documented switches of the product
+        assert kept in blob, kept
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert not [s for s in native.SYMBOLS_DIAG if s in nm]
 
 
 def test_layout_struct_matches_header():

@@ -150,7 +150,7 @@ def test_one_wave_per_kitchen_geometry(layout_params):
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 63, 64, 65])
 def test_small_and_ragged_sizes(n, layout_params, monkeypatch):
     if n % 2:
-        monkeypatch.setenv("OC_ALIGNED_PASSES", "1")      # odd sizes also exercise the kitchen-aligned pass mode
+        monkeypatch.setenv("OC_ALIGNED_PASSES", "1")      # (diagnostics build only: odd sizes then also exercise the kitchen-aligned pass mode)
     for layout in ("simple", "random0", "unident_s"):
         params = layout_params[layout]
         acts = _mixed_actions(layout, 210, n, seed=n)
@@ -267,7 +267,8 @@ def test_time_major_steps_of_a_large_small_grid_batch_use_their_own_geometry(lay
     acts = rng.integers(0, 6, size=(3 * T, 2, n)).astype(np.int32)
     dacts = torch.from_numpy(acts).cuda()
     eng = _engine(params, n)
-    assert "kpw 32" in eng.kernel_build_info
+    if "specialised" in eng.kernel_build_info:       # (OC_NO_JIT=1 runs this file on the generic ahead-of-time kernel: no per-engine geometry string)
+        assert "kpw 32" in eng.kernel_build_info
     eng.prepare_kernels()                        # the time-major and fused-rollout modules, ahead of their first use (idempotent)
     eng.prepare_kernels()
     ora = oracle.OracleVecEnv(params, len(pick))
@@ -575,3 +576,16 @@ def test_hip_replays_the_reference_syncvectorenv_recording(layout_params):
         assert np.array_equal(vobs.obs.cpu().numpy(), rec["obs"][t][0]), t
         assert np.array_equal(rew.cpu().numpy(), rec["reward"][t][0]) and np.array_equal(done.cpu().numpy().astype(np.uint8), rec["done"][t])
     env.close()
+
+
+def test_this_whole_file_on_the_generic_ahead_of_time_kernel(clean_launcher):
+    """A box where hiprtc is unusable serves every engine with the generic ahead-of-time kernel (every layout parameter a runtime
+    field).  The driver never sets OC_NO_JIT, so this test does: the whole parity file again, in a child process, on that kernel."""
+    import os
+    import sys
+    if os.environ.get("OC_NO_JIT", "0") not in ("", "0"):
+        pytest.skip("already running on the generic kernel")
+    r = clean_launcher.run([sys.executable, "-m", "pytest", "tests/test_hip_parity.py", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                           env={"OC_NO_JIT": "1"}, timeout=1100)
+    tail = r["stdout"][-1500:] + r["stderr"][-500:]
+    assert r["rc"] == 0 and " passed" in r["stdout"] and "failed" not in r["stdout"], tail

@@ -11,6 +11,10 @@ from conftest import ROOT
 
 
 def test_host_code_of_the_product_library_runs_clean_under_asan_ubsan():
+    import pytest
+    rt = subprocess.run(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    if rt.returncode != 0 or not os.path.isabs(rt.stdout.strip()) or not os.path.exists(rt.stdout.strip()):
+        pytest.skip("this toolchain ships no ASan runtime (hipcc -print-file-name=libclang_rt.asan-x86_64.so does not resolve)")
     env = {k: v for k, v in os.environ.items() if k not in ("OC_SANITIZE", "LD_PRELOAD")}
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "run_sanitized.sh"), "-x"], capture_output=True, text=True, timeout=1700, env=env, cwd=ROOT)
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B of launch geometries for the headline workload (cramped_room, 65 536 kitchens, in place): each candidate is
 re-measured `rounds` times in rotation so that drift between engines / clocks averages out.  Prints median and min us/launch."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

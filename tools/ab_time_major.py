@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Launch geometries for the time-major destination (every step's planes into their own slot, non-temporal stores):
 interleaved A/B like tools/ab_geometry.py.  Candidates kpw,passes,wpc[,fast flush[,fresh store mode]]."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,6 +2,8 @@
 """Phase-cost diagnostics for the fused step kernel (timing only, outputs are wrong when a phase is
 skipped): OC_ABLATE bits 1=skip transition 2=skip obs stores 4=skip encode compute 8=skip state
 write-back 16=skip state load."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import os
 import sys
 

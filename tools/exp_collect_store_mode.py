@@ -3,6 +3,8 @@
 fresh slots: write-through non-temporal (the default for fresh destinations, best for the env launch alone) against plain
 write-through -- the NEXT launch is the policy kernel, which reads those very planes.  Run once per OC_STORE_MODE (read at
 oc_create): OC_STORE_MODE=2,4 (default) / 2,2 / 2,1 / 2,0."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

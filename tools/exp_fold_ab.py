@@ -4,6 +4,8 @@ policy launch, OC_POLICY_FOLD=1), us per step:
     python tools/exp_fold_ab.py [layout] [kitchens]
 Lines: fold 0 = two launches; fold 1 = one launch; debug 2 = one launch WITHOUT the env call (what the arrival bookkeeping costs;
 results wrong by design); debug 4 = the env call made twice (is a call slow because its code is cold? no: twice the time)."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """EXPERIMENT: phase stamps (s_memrealtime, 100 MHz) of the env step body when it runs folded into the policy launch
 (OC_POLICY_FOLD=1, OC_FOLD_TRACE=1): one sample per workgroup (the last env call of the launch), phases as tools/trace_phases.py."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import ctypes, os, sys
 os.environ["OC_FOLD_TRACE"] = "1"
 os.environ["OC_POLICY_FOLD"] = "1"

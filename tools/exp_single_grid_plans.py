@@ -2,6 +2,8 @@
 """Config 4's per-GPU share (asymmetric_advantages, 8184 kitchens, 16 conventions = 31 segments of 264 kitchens, actors + critics)
 with the policies in the loop: the single-grid plan of FusedPairedRollout against the multi-grid planner run on one grid
 (GroupPairedRollout over a one-engine group: packed stretches / wave tiles), OC_POLICY_WAVE_TILES=0/1 forcing either."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: store mode of the plane stores (plain / nt / sc1 / sc0 sc1, see store16) x batch shape.
 OC_STORE_MODE is read when a kernel is specialised, so every measurement builds fresh engines."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import json
 import os
 import sys

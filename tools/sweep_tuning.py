@@ -2,6 +2,8 @@
 """Launch-geometry sweep for the fused step kernel: kitchens-per-wave x staging-passes-per-flush.
 Prints us/launch and achieved algorithmic GB/s per configuration (performance only; results are
 identical for every setting -- tests/test_hip_parity.py::test_tuning_does_not_change_results)."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import argparse
 import os
 import sys

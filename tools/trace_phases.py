@@ -3,6 +3,8 @@
 Stamps: 0 wave start, 1 prologue done (tables + first state block landed), 2 first transition done,
 3 first plane flush issued, 4 last plane flush issued, 5 wave end.  Times in us relative to the
 earliest wave start."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import ctypes
 import os
 import sys

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-wavefront phase timeline of ONE oc_policy_forward launch (s_memrealtime stamps, 100 MHz, of each wave's
 FIRST 32-row block; plus the shader clock over the wave's whole life).  Diagnostic only."""
+import os as _os
+_os.environ.setdefault("OC_DIAGNOSTICS", "1")      # phase stamps / ablation / experiment knobs live in csrc/liboc_hip_diag.so only
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
