@@ -110,7 +110,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     // ---- software pipeline: registers hold the *next* group's state block and actions
     // Loads are unconditional (indices clamped into the arrays) so that they land directly in the
     // pipeline registers: a predicated load would be copied -- and therefore waited for -- on the spot.
-    uint4 pre[QN];
+    // (one 128-bit vector value per chunk, not a struct of four words: the landing below then ties ONE register tuple per chunk.  As
+    // four separately tied words -- rounds 1-3 -- hipcc 7.2 dropped the copies of two of them in one build of the generic kernel and
+    // the second group of a wavefront wrote stale words into its last two kitchens: found in round 4, when the whole parity file first
+    // ran on that kernel at a size where wavefronts take two groups)
+    u32x4 pre[QN];
     int pa0, pa1;
     const int64_t last_chunk = KP_n_kitchens(a) * KP_recq(a) - 1;
     // group -> (batch item, first kitchen of the group inside the item); one item unless BATCH
@@ -120,7 +124,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
         const int item = item_of(g);
         const int64_t k0 = first_kitchen(g, item);
         const int64_t c0 = k0 * KP_recq(a) + lane;
-        const uint4 *st = a.state + (BATCH ? item * a.state_batch_stride : 0);
+        const u32x4 *st = reinterpret_cast<const u32x4 *>(a.state + (BATCH ? item * a.state_batch_stride : 0));
 #pragma unroll
         for (int q = 0; q < QN; ++q) pre[q] = st[min(c0 + q * kWave, last_chunk)];
         if (STEP) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     // order, so a wait for these loads placed after plane stores have been issued also waits for the stores.
     auto land_prefetch = [&]() {
 #pragma unroll
-        for (int q = 0; q < QN; ++q) asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w));
+        for (int q = 0; q < QN; ++q) asm volatile("" : "+v"(pre[q]));
         asm volatile("" : "+v"(pa0), "+v"(pa1));
     };
     unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -153,18 +157,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     // the state loads, in front of everything a wavefront does (seen in the code object of the specialised build).
     int group = block_id;
     {
-        const uint4 *img = reinterpret_cast<const uint4 *>(a.tabs);
+        const u32x4 *img = reinterpret_cast<const u32x4 *>(a.tabs);
         const int nq4 = lds_table_dwords(S, KP_n_pots(a), KP_n_counters(a)) / 4;
-        uint4 tq[kTabQ];
+        u32x4 tq[kTabQ];
 #pragma unroll
         for (int q = 0; q < kTabQ; ++q) tq[q] = img[min(lane + q * kWave, nq4 - 1)];
         prefetch(min(group, KP_n_groups(a) - 1));                 // the first group's loads: in flight during the table setup
 #pragma unroll
-        for (int q = 0; q < kTabQ; ++q) asm volatile("" : "+v"(tq[q].x), "+v"(tq[q].y), "+v"(tq[q].z), "+v"(tq[q].w));
+        for (int q = 0; q < kTabQ; ++q) asm volatile("" : "+v"(tq[q]));
 #pragma unroll
         for (int q = 0; q < kTabQ; ++q)
-            if (lane + q * kWave < nq4) reinterpret_cast<uint4 *>(lds)[lane + q * kWave] = tq[q];
-        for (int c = lane + kTabQ * kWave; c < nq4; c += kWave) reinterpret_cast<uint4 *>(lds)[c] = img[c];   // huge layouts only
+            if (lane + q * kWave < nq4) reinterpret_cast<u32x4 *>(lds)[lane + q * kWave] = tq[q];
+        for (int c = lane + kTabQ * kWave; c < nq4; c += kWave) reinterpret_cast<u32x4 *>(lds)[c] = img[c];   // huge layouts only
     }
 
     // where this lane's q-th 16-byte chunk of a group's state block lives in LDS (group independent)

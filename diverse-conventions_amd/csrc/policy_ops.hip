@@ -129,7 +129,7 @@ struct PolicyArgs {
 };
 
 // (phase stamps exist in the diagnostics build only; in the product library the calls compile to nothing)
-#ifdef OC_DIAGNOSTICS
+#if defined(OC_DIAGNOSTICS) || defined(OC_FORCE_STAMPS)
 constexpr bool kPolicyTrace = true;
 #else
 constexpr bool kPolicyTrace = false;
@@ -303,11 +303,14 @@ __device__ __forceinline__ v16f mfma_bf16(const v4i a, const v4i b, const v16f c
 __device__ constexpr int kTermW[6] = {0, 0, 1, 0, 1, 2};
 __device__ constexpr int kTermX[6] = {0, 1, 0, 2, 1, 0};
 
-// max(x, 0) of an MFMA result in ONE instruction (fmaxf first quiets a possible signalling NaN with a second v_max)
+// max(x, 0) of an MFMA result in ONE instruction (fmaxf first quiets a possible signalling NaN with a second v_max): v_med3_f32
+// against 0 and FLT_MAX through the builtin.  NOT inline asm: a VALU instruction that reads a register an MFMA has just written needs up
+// to 19 wait states behind it on gfx950, the compiler's hazard recogniser inserts them for instructions it can see and does not look
+// inside asm -- as `asm("v_max_f32 ...")` (rounds 2-3) the first relu behind fc2's last MFMA read a stale accumulator whenever nothing
+// else happened to be scheduled in between: the wave-tile build of the product library (no LDS read there, and no phase stamps since
+// round 4) returned values off by up to 0.1 until this was found.
 __device__ __forceinline__ float relu(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
+    return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234664e38f);      // (FLT_MAX, not +inf: against +inf the compiler folds the median into a max and adds the quieting v_max back)
 }
 
 // Two f32 activations -> one packed dword per bf16 piece, x = hi + mid + lo exactly: the top 16 bits of an f32 are a
