@@ -574,7 +574,7 @@ def main():
           step_modes["two_launches_time_major_slots"] = (time.perf_counter() - t1) / 600 * 1e6
           del ctraj
           rows = 2 * eng2.num_kitchens
-          cycles = rows / 32 * 32 * (P * (6 * nets.digits + 24) + 48 + 24)     # MFMA issue cycles (i8 conv digits + bf16 piece products), DESIGN 9a
+          cycles = rows / 32 * 32 * (P * (6 * nets.digits + 12) + 24 + 12)     # MFMA issue cycles (i8 conv digits + f16 two-piece products), DESIGN 9a
           cus = torch.cuda.get_device_properties(local).multi_processor_count
           bound_us = cycles / (4 * cus) / 2400.0
           policy = {"what": f"{k + 1} conventions in {2 * k + 1} pairing segments of {threads} kitchens: every actor, both sides, in one "
@@ -587,9 +587,9 @@ def main():
                     "policy_kernel": {"kernel": f"oc_policy_kernel<{nets.digits} digits>", "us_per_launch": pol_us, "network_evaluations": rows,
                                       "useful_TFLOPs": rows * 2 * (P * 180 * 32 + P * 32 * 64 + 64 * 64 + 64 * 6) / pol_us * 1e-6,
                                       "bound": "mfma", "issue_bound_us_at_2.4GHz": bound_us, "frac": bound_us / pol_us,
-                                      "note": "matrix cycles per 32 rows: 10 368 (three base-256 i8 conv digits + bf16 piece products for the dense "
-                                              "layers; 11 520 with four base-128 digits in round 2, 23 040 with f32 MFMAs in round 1); the VALU work "
-                                              "between the layers does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
+                                      "note": "matrix cycles per 32 rows: 6912 (three base-256 i8 conv digits + f16 two-piece products -- hi hi, hi lo, lo hi -- for "
+                                              "the dense layers; 10 368 with three bf16 pieces in round 3, 11 520 in round 2, 23 040 with f32 MFMAs in round 1); the VALU "
+                                              "work between the layers does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
           eng2.close()
       except Exception as exc:                             # noqa: BLE001
         policy = {"error": f"{type(exc).__name__}: {exc}"}

@@ -84,14 +84,14 @@
             bhq = *reinterpret_cast<const v4f *>(bh);
         }
         // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
-        auto make_operand = [&](v4i (&dst)[3][2], int j) {            // pair j = accumulator registers 2j, 2j + 1
-            int hi, mid, lo;
+        auto make_operand = [&](v4i (&dst)[kPieces][2], int j) {      // pair j = accumulator registers 2j, 2j + 1
+            int hi, lo;
             float x0, x1;
             combine_pair(acc, 2 * j, x0, x1);
-            split_pair(x0, x1, hi, mid, lo);
-            dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = mid; dst[2][j >> 2][j & 3] = lo;
+            split_pair(x0, x1, hi, lo);
+            dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = lo;
         };
-        v4i xb[3][2];
+        v4i xb[kPieces][2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) make_operand(xb, j);
         if (traced2) stamp(a, wave, lane, 19);
@@ -99,19 +99,19 @@
         // fc1 fragments of a position [piece][k-group][out half].  They are requested one position ahead, into the registers
         // the MFMAs of the current position have just read, so an L2 round trip (fc1 not LDS-resident) has the operand
         // conversion and the next conv to land in.
-        v4i w1r[3][2][2];
+        v4i w1r[kPieces][2][2];
         auto load_w1 = [&](int p) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < kPieces; ++q)
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo)
-                        w1r[q][g][mo] = FC1_LDS ? w1l[(p * 12 + (q * 2 + g) * 2 + mo) * 64]
+                        w1r[q][g][mo] = FC1_LDS ? w1l[(p * (4 * kPieces) + (q * 2 + g) * 2 + mo) * 64]
                                                 : w1_from_l2(w1g, lane16, p, (q * 2 + g) * 2 + mo);
         };
         load_w1(p_first);
-        // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x six piece products x two
+        // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x three piece products x two
         // output halves.  Unless it is the last, the next position's operand is built around them: the second k-group's
         // registers (pairs 4..7) into spare registers next to the first group's MFMAs, the first group's (pairs 0..3) in place
         // once its MFMAs have issued.
@@ -125,23 +125,26 @@
                 read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
             }
             __builtin_amdgcn_sched_barrier(0);
-            v4i nb1[3];
+            v4i nb1[kPieces];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                h1[0] = mfma_bf16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
-                h1[1] = mfma_bf16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
-                if (!kLast && t < 4) {
-                    int hi, mid, lo;
-                    float x0, x1;
-                    combine_pair(acc, 8 + 2 * t, x0, x1);
-                    split_pair(x0, x1, hi, mid, lo);
-                    nb1[0][t] = hi; nb1[1][t] = mid; nb1[2][t] = lo;
+            for (int t = 0; t < kTerms; ++t) {
+                h1[0] = mfma_f16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
+                h1[1] = mfma_f16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
+                if (!kLast) {                                          // pairs 4..7 of the next operand, spread over the three terms: 2, 1, 1
+#pragma unroll
+                    for (int u = (t == 0 ? 0 : t + 1); u < (t == 0 ? 2 : t + 2); ++u) {
+                        int hi, lo;
+                        float x0, x1;
+                        combine_pair(acc, 8 + 2 * u, x0, x1);
+                        split_pair(x0, x1, hi, lo);
+                        nb1[0][u] = hi; nb1[1][u] = lo;
+                    }
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                h1[0] = mfma_bf16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
-                h1[1] = mfma_bf16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
+            for (int t = 0; t < kTerms; ++t) {
+                h1[0] = mfma_f16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
+                h1[1] = mfma_f16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
             }
             if (!kLast) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -150,7 +153,7 @@
 #pragma unroll
                 for (int t = 0; t < 4; ++t) make_operand(xb, t);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) xb[q][1] = nb1[q];
+                for (int q = 0; q < kPieces; ++q) xb[q][1] = nb1[q];
             }
             if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
         };
@@ -208,28 +211,29 @@
 
         // ---- fc2: h2^T[n2][row] = b2 + W2 relu(h1): four k-groups (input half kg >> 1, registers 8 (kg & 1) ..) ----
         // the operand pieces of k-group kg + 1 are built under the MFMAs of k-group kg
-        auto split_group = [&](const v16f &v, int g, v4i (&dst)[3]) {  // relu + split of registers 8g .. 8g + 7
+        auto split_group = [&](const v16f &v, int g, float descale, v4i (&dst)[kPieces]) {  // descale (a power of two: the layer's weight up-scale off again), relu + clamp, split of registers 8g .. 8g + 7
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int hi, mid, lo;
-                split_pair(relu(v[8 * g + 2 * j]), relu(v[8 * g + 2 * j + 1]), hi, mid, lo);
-                dst[0][j] = hi; dst[1][j] = mid; dst[2][j] = lo;
+                int hi, lo;
+                const v2f t = v2f{v[8 * g + 2 * j], v[8 * g + 2 * j + 1]} * v2f{descale, descale};
+                split_pair(relu_clamp(t.x), relu_clamp(t.y), hi, lo);
+                dst[0][j] = hi; dst[1][j] = lo;
             }
         };
         // weight fragments: from LDS one k-group ahead; from L2 (wave tiles) all four k-groups at once, and the head's as well,
         // half-way through fc2 -- twelve MFMAs (0.2 us) do not cover an L2 round trip
         constexpr int WB = TAIL_LDS ? 2 : 4;                          // fragment buffers
-        v4i whr[WB][3];
+        v4i whr[WB][kPieces];
         auto load_wh = [&](int kg) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) whr[kg % WB][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
+            for (int q = 0; q < kPieces; ++q) whr[kg % WB][q] = head_lane ? wh[(q * 4 + kg) * 16] : v4i{0, 0, 0, 0};
         };
         {
-            v4i hb[2][3];                                             // [parity of kg][piece]
-            v4i w2r[WB][3][2];                                        // [kg % WB][piece][out half]
+            v4i hb[2][kPieces];                                       // [parity of kg][piece]
+            v4i w2r[WB][kPieces][2];                                  // [kg % WB][piece][out half]
             auto load_w2 = [&](int kg) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < kPieces; ++q)
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo) w2r[kg % WB][q][mo] = w2[((q * 4 + kg) * 2 + mo) * 64];
             };
@@ -238,7 +242,7 @@
 #pragma unroll
                 for (int kg = 1; kg < 4; ++kg) load_w2(kg);
             }
-            split_group(h1[0], 0, hb[0]);
+            split_group(h1[0], 0, ds1, hb[0]);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 if (TAIL_LDS && kg + 1 < 4) load_w2(kg + 1);
@@ -247,32 +251,33 @@
                     for (int k2 = 0; k2 < 4; ++k2) load_wh(k2);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    h2[0] = mfma_bf16(w2r[kg % WB][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
-                    h2[1] = mfma_bf16(w2r[kg % WB][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
+                for (int t = 0; t < kTerms; ++t) {
+                    h2[0] = mfma_f16(w2r[kg % WB][kTermW[t]][0], hb[kg & 1][kTermX[t]], h2[0]);
+                    h2[1] = mfma_f16(w2r[kg % WB][kTermW[t]][1], hb[kg & 1][kTermX[t]], h2[1]);
                 }
-                if (kg + 1 < 4) split_group(h1[(kg + 1) >> 1], (kg + 1) & 1, hb[(kg + 1) & 1]);
+                if (kg + 1 < 4) split_group(h1[(kg + 1) >> 1], (kg + 1) & 1, ds1, hb[(kg + 1) & 1]);
             }
         }
         if (traced) stamp(a, wave, lane, 5);
         if (traced2) stamp(a, wave, lane, 28);
         // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; two accumulators so consecutive MFMAs do not wait for each other ----
         {
-            v4i gb[2][3];
+            v4i gb[2][kPieces];
             if (TAIL_LDS) load_wh(0);
-            split_group(h2[0], 0, gb[0]);
+            split_group(h2[0], 0, ds2, gb[0]);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 if (TAIL_LDS && kg + 1 < 4) load_wh(kg + 1);
+                // (twelve MFMAs in all: alternating between two accumulators so consecutive ones do not wait for each other)
 #pragma unroll
-                for (int t = 0; t < 6; t += 2) {
-                    out = mfma_bf16(whr[kg % WB][kTermW[t]], gb[kg & 1][kTermX[t]], out);
-                    out2 = mfma_bf16(whr[kg % WB][kTermW[t + 1]], gb[kg & 1][kTermX[t + 1]], out2);
+                for (int t = 0; t < kTerms; ++t) {
+                    if ((kg * kTerms + t) & 1) out2 = mfma_f16(whr[kg % WB][kTermW[t]], gb[kg & 1][kTermX[t]], out2);
+                    else out = mfma_f16(whr[kg % WB][kTermW[t]], gb[kg & 1][kTermX[t]], out);
                 }
-                if (kg + 1 < 4) split_group(h2[(kg + 1) >> 1], (kg + 1) & 1, gb[(kg + 1) & 1]);
+                if (kg + 1 < 4) split_group(h2[(kg + 1) >> 1], (kg + 1) & 1, ds2, gb[(kg + 1) & 1]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] += out2[r];
+            for (int r = 0; r < 4; ++r) out[r] = (out[r] + out2[r]) * ds3;         // the head's weight and operand scales off again
         }
         if (traced) stamp(a, wave, lane, 6);
         if (traced2) stamp(a, wave, lane, 29);

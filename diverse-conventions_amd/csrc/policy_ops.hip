@@ -12,18 +12,19 @@
 //               base-256 fixed-point digits per output channel (policy_pack.h).  Integer accumulation is exact;
 //               with 3 digits the weight quantisation (2^-23 of the channel's largest weight: the f32 spacing of
 //               that weight) is of the class of the f32 rounding of the reference's own accumulation.
-//   fc1/fc2/head : v_mfma_f32_32x32x16_bf16 on exact three-way bf16 splits of both operands (six piece products per
-//               f32 product, f32 accumulate; policy_pack.h): what is dropped is below 2^-23 of each product, and a
-//               32x32x16 tile costs 6 x 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64.  The weights are split at
-//               pack time, the activations in the kernel (two AND, two exact subtractions, three byte permutes per
-//               register pair).
+//   fc1/fc2/head : v_mfma_f32_32x32x16_f16 on two-way f16 splits of both operands (round to nearest: hi + lo carries 2^-24 of
+//               the value, f32's own precision, as long as the low piece is a normal f16 number -- arranged with power-of-two
+//               scales per layer, policy_pack.h), three piece products per f32 product (hi hi, hi lo, lo hi), f32 accumulate:
+//               a 32x32x16 tile costs 3 x 32 cycles where rounds 2-3 (three bf16 pieces, six products) paid 6 x 32 and
+//               v_mfma_f32_32x32x2_f32 needs 8 x 64.  The weights are split at pack time, the activations in the kernel: two
+//               packed conversions and two v_fma_mix per register pair.
 // Everything is evaluated transposed (feature index on the accumulator registers, row on the lanes): the output
 // of one layer is then directly the B operand of the next, with no lane movement and no LDS round trip.
 //
 // Bound: MFMA issue + the VALU work between the layers (tools/probes/coexec.hip: they do not overlap on one SIMD).
-// MFMA cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 24*32) + 48*32 + 24*32; cramped_room
-// (P = 6, 3 digits) 10 368 cycles (11 520 with four base-128 digits in round 2, 23 040 with f32 MFMAs for the dense layers in round 1).  Bytes: rows are read
-// once (W*H*20 B each).
+// MFMA cycles per 32 rows on one SIMD (P conv positions): P*(6*digits*32 + 12*32) + 24*32 + 12*32; cramped_room
+// (P = 6, 3 digits) 6912 cycles (10 368 with three bf16 pieces in round 3, 11 520 with four base-128 digits in round 2, 23 040 with f32
+// MFMAs for the dense layers in round 1).  Bytes: rows are read once (W*H*20 B each).
 //
 // Shape of the kernel (DESIGN.md 9a has the measurements behind each choice):
 //   * a workgroup = up to 8 wavefronts (two per SIMD; the kernel is held to 256 VGPRs and built with
@@ -62,7 +63,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
 constexpr int kRowsPerBlock = 32;       // rows per wavefront pass = MFMA column count
 #ifdef OC_DIAGNOSTICS
@@ -295,64 +297,41 @@ __device__ __forceinline__ void read_bfrags(const uint8_t *rowp, int pos_off, in
         }
 }
 
-// One dense-layer tile step: D += A (weight pieces, 8 bf16 per lane) x B (activation pieces, 8 bf16 per lane)
-__device__ __forceinline__ v16f mfma_bf16(const v4i a, const v4i b, const v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+// One dense-layer tile step: D += A (weight pieces, 8 f16 per lane) x B (activation pieces, 8 f16 per lane)
+__device__ __forceinline__ v16f mfma_f16(const v4i a, const v4i b, const v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
 }
-// The six piece products kept of (w0 + w1 + w2) * (x0 + x1 + x2): weight piece, activation piece
-__device__ constexpr int kTermW[6] = {0, 0, 1, 0, 1, 2};
-__device__ constexpr int kTermX[6] = {0, 1, 0, 2, 1, 0};
+// The three piece products kept of (w_hi + w_lo) * (x_hi + x_lo): weight piece, activation piece (lo * lo is below 2^-24 of the product)
+constexpr int kPieces = OC_POLICY_PIECES, kTerms = 3;
+__device__ constexpr int kTermW[kTerms] = {0, 0, 1};
+__device__ constexpr int kTermX[kTerms] = {0, 1, 0};
 
-// max(x, 0) of an MFMA result in ONE instruction (fmaxf first quiets a possible signalling NaN with a second v_max): v_med3_f32
-// against 0 and FLT_MAX through the builtin.  NOT inline asm: a VALU instruction that reads a register an MFMA has just written needs up
-// to 19 wait states behind it on gfx950, the compiler's hazard recogniser inserts them for instructions it can see and does not look
-// inside asm -- as `asm("v_max_f32 ...")` (rounds 2-3) the first relu behind fc2's last MFMA read a stale accumulator whenever nothing
-// else happened to be scheduled in between: the wave-tile build of the product library (no LDS read there, and no phase stamps since
-// round 4) returned values off by up to 0.1 until this was found.
-__device__ __forceinline__ float relu(float x) {
-    return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234664e38f);      // (FLT_MAX, not +inf: against +inf the compiler folds the median into a max and adds the quieting v_max back)
+// An activation as a dense-layer operand: relu, and the clamp to f16's largest finite number, in ONE instruction -- v_med3_f32 through
+// the builtin.  NOT inline asm: a VALU instruction that reads a register an MFMA has just written needs up to 19 wait states behind it
+// on gfx950, the compiler's hazard recogniser inserts them for instructions it can see and does not look inside asm -- as
+// `asm("v_max_f32 ...")` (rounds 2-3) the first relu behind fc2's last MFMA read a stale accumulator whenever nothing else happened to
+// be scheduled in between: the wave-tile build of the product library (no LDS read there, and no phase stamps since round 4) returned
+// values off by up to 0.1 until this was found.  (fmaxf would first quiet a possible signalling NaN with a second v_max.)
+__device__ __forceinline__ float relu_clamp(float x) {
+    return __builtin_amdgcn_fmed3f(x, 0.0f, OC_POLICY_F16_MAX);
 }
 
-// Two f32 activations -> one packed dword per bf16 piece, x = hi + mid + lo exactly: the top 16 bits of an f32 are a
-// bf16 (truncation), what is left after subtracting it has at most 16 significant bits, and so on.  The byte permute that
-// packs the two truncated values comes first; taking them off again is ONE instruction per value, v_dot2c_f32_bf16
-// (acc += a.lo * b.lo + a.hi * b.hi) against the constants {-1, 0} / {0, -1}: the products are exact and x - trunc(x) is
-// representable, so no rounding can show (tools/probes/split_bf16.hip compares it bit for bit with the AND / subtract form
-// on 2^25 pairs).  7 VALU per pair where two AND + one packed subtract per level + three permutes cost 9.
-#ifndef OC_SPLIT_DOT2C
-#define OC_SPLIT_DOT2C 1
-#endif
-typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair(float x0, float x1, int &hi, int &mid, int &lo) {
-#if OC_SPLIT_DOT2C
-    // {-1, 0} and {0, -1}, kept in SGPRs behind an empty asm: as a plain constant hipcc 7.2 folds 0x0000bf80 into the inline
-    // operand "-1.0", which the instruction reads as the f32 pattern 0xbf800000 = {0, -1} -- the other constant
-    // (tools/probes/split_bf16.hip caught it: every first element's remainder came out as x0 - trunc(x1))
-    uint32_t k_lo = 0x0000bf80u, k_hi = 0xbf800000u;
-    asm volatile("" : "+s"(k_lo), "+s"(k_hi));
-    const v2bf m_lo = __builtin_bit_cast(v2bf, k_lo), m_hi = __builtin_bit_cast(v2bf, k_hi);
-    const uint32_t h = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, h), m_lo, x0, false);
-    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, h), m_hi, x1, false);
-    const uint32_t m = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-    const float q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, m), m_lo, r0, false);
-    const float q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, m), m_hi, r1, false);
-    hi = static_cast<int>(h);
-    mid = static_cast<int>(m);
-    lo = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u));
-#else
+// Two f32 activations (already relu'd, clamped and in the operand scale) -> one packed dword per f16 piece, x = hi + lo to 2^-24 of x:
+// hi = f16(x) and lo = f16(x - hi), both round to nearest even (v_cvt_pk_f16_f32); the remainder is exact (v_fma_mix_f32 reads the f16
+// half as an f32 operand: fma(hi, -1, x), one instruction per value).  4 VALU per pair where the three-way bf16 split cost 7.
+__device__ __forceinline__ void split_pair(float x0, float x1, int &hi, int &lo) {
     const v2f xv = {x0, x1};
-    const v2f hv = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
-    const v2f rv = xv - hv;
-    const v2f mv = {__uint_as_float(__float_as_uint(rv.x) & 0xffff0000u), __uint_as_float(__float_as_uint(rv.y) & 0xffff0000u)};
-    const v2f qv = rv - mv;
-    hi = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u));
-    mid = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(rv.y), __float_as_uint(rv.x), 0x07060302u));
-    lo = static_cast<int>(__builtin_amdgcn_perm(__float_as_uint(qv.y), __float_as_uint(qv.x), 0x07060302u));
-#endif
+    const v2h h = __builtin_convertvector(xv, v2h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+    const v2f rv = {r0, r1};
+    const v2h l = __builtin_convertvector(rv, v2h);
+    hi = __builtin_bit_cast(int, h);
+    lo = __builtin_bit_cast(int, l);
 }
 
-// fragment f (0..11) of position p of the fc1 section: voffset = lane * 16 (+ immediate), soffset scalar
+// fragment f (0..7) of position p of the fc1 section: voffset = lane * 16 (+ immediate), soffset scalar
 __device__ __forceinline__ v4i w1_from_l2(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane16, int p, int f) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(lane16) + (f & 3) * 1024,
                                                          p * OC_POLICY_FC1_POS_BYTES + (f >> 2) * 4096, 0);
@@ -606,31 +585,37 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     const uint8_t *rowp = ldsw + col * RB + 16 * h;
     int colstep = H * OC_POLICY_C;
     int loaded_net = -1, loaded_slot = 0, n_out = 1;
+    // the loaded network's descale factors (powers of two, policy_pack.h): fc1 accumulators -> fc2 operand, fc2 -> head operand, head -> outputs
+    float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     bool trace_done = false, trace2_done = false;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
-    // conv result -> fc1 operand: relu(f32(sum of digit accumulators)), two accumulator registers at a time.  The channel's bias
-    // is already in the sum (the lowest digit's accumulator starts from it) and its scale is folded into the fc1 weights.
-    // The top digit pair is combined in integer arithmetic (acc_0 * B + acc_1: exact, |.| < 2^31), so three digits cost
-    // 1 shift-add + 2 conversions + half a packed fma per register: a wave's VALU work is not hidden under its MFMAs.
+    // conv result -> fc1 operand: relu(2^-shift x f32(sum of digit accumulators)), two accumulator registers at a time.  The channel's
+    // bias is already in the sum (the lowest digit's accumulator starts from it) and its scale is folded into the fc1 weights; the
+    // power of two brings the integer sums (up to 2^31) into f16's range for the split (oc_policy_conv_shift: exact, and the same for
+    // every channel, so it is a constant of the packed multiplies here, not a per-register value).  The top digit pair is combined in
+    // integer arithmetic (acc_0 * B + acc_1: exact, |.| < 2^31), so three digits cost 1 shift-add + 2 conversions + two halves of a
+    // packed multiply / fma per register: a wave's VALU work is not hidden under its MFMAs.
     auto combine_pair = [&](const v16i (&acc)[NDIG], int r, float &x0, float &x1) {
         constexpr int kB = OC_POLICY_DIGIT_BASE;
+        const float sc = oc_pow2f(-oc_policy_conv_shift(NDIG));
         v2f t;
         if (NDIG == 1) {
-            t = v2f{static_cast<float>(acc[0][r]), static_cast<float>(acc[0][r + 1])};
+            t = v2f{static_cast<float>(acc[0][r]), static_cast<float>(acc[0][r + 1])} * v2f{sc, sc};
         } else {
             t = v2f{static_cast<float>(acc[0][r] * kB + acc[1][r]), static_cast<float>(acc[0][r + 1] * kB + acc[1][r + 1])};
+            if (NDIG == 2) t = t * v2f{sc, sc};
             if (NDIG == 3) {
-                const v2f u = {static_cast<float>(acc[2][r]), static_cast<float>(acc[2][r + 1])};
-                t = __builtin_elementwise_fma(t, v2f{static_cast<float>(kB), static_cast<float>(kB)}, u);
+                const v2f u = v2f{static_cast<float>(acc[2][r]), static_cast<float>(acc[2][r + 1])} * v2f{sc, sc};
+                t = __builtin_elementwise_fma(t, v2f{kB * sc, kB * sc}, u);
             }
             if (NDIG == 4) {
-                const v2f u = {static_cast<float>(acc[2][r] * kB + acc[3][r]), static_cast<float>(acc[2][r + 1] * kB + acc[3][r + 1])};
-                t = __builtin_elementwise_fma(t, v2f{static_cast<float>(kB * kB), static_cast<float>(kB * kB)}, u);
+                const v2f u = v2f{static_cast<float>(acc[2][r] * kB + acc[3][r]), static_cast<float>(acc[2][r + 1] * kB + acc[3][r + 1])} * v2f{sc, sc};
+                t = __builtin_elementwise_fma(t, v2f{kB * kB * sc, kB * kB * sc}, u);
             }
         }
-        x0 = relu(t.x);
-        x1 = relu(t.y);
+        x0 = relu_clamp(t.x);
+        x1 = relu_clamp(t.y);
     };
     auto conv = [&](v16i (&acc)[NDIG], const v4i (&bfr)[6]) {
 #pragma unroll
@@ -793,6 +778,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     int tail_bytes = 0;
     bool weights_in_lds = false;
     int hdr_n_out = 0;
+    int hdr_d1 = 0, hdr_d2 = 0, hdr_d3 = 0;
     // (two passes through ONE copy of the row-staging code -- early rows, weights, late rows; a second inlined copy of stage_rows
     // costs the 256-register build SGPR spills it has no lane left for)
 #pragma unroll 1
@@ -805,13 +791,17 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         if (loaded_net < 0) stamp(a, wave, lane, 11);
         if (loaded_net >= 0) __syncthreads();                         // everybody is done with the previous network
         blob = S.packed + static_cast<size_t>(net) * S.L.total;
-        if (a.lds_weight_bytes == 0) hdr_n_out = reinterpret_cast<const int *>(blob)[4];   // (wave tiles: requested here, used behind the barrier)
+        if (a.lds_weight_bytes == 0) {                                // (wave tiles: requested here, used behind the barrier)
+            hdr_n_out = reinterpret_cast<const int *>(blob)[4];
+            const int *dg = reinterpret_cast<const int *>(blob + S.L.off_ds);
+            hdr_d1 = dg[0]; hdr_d2 = dg[1]; hdr_d3 = dg[2];
+        }
         // LDS-resident weights, verbatim pieces of the image: [conv digits + scale/bias] when CONV_LDS, then the
         // tail from fc1 (or, when fc1 does not fit, from b1) to the end, each padded to whole KB in LDS.  LDS-DMA: every piece is
         // in flight at once (a load / wait / ds_write loop cost one L2 round trip per pass); see copy_to_lds.  The lanes past the
         // tail's end bring the image HEADER along: the network's own output count (header word 4) is then an LDS read behind the
         // barrier instead of a scalar load that was waited for on the spot, one more round trip in front of the copy.
-        tail_bytes = static_cast<int>(S.L.off_bh + 32 - wstart);
+        tail_bytes = static_cast<int>(S.L.off_ds + 32 - wstart);
         weights_in_lds = a.lds_weight_bytes > 0;
         if (weights_in_lds) {
             // (the wavefront index behind an empty asm: everything copy_to_lds derives from it is then computed here, where it is used --
@@ -850,6 +840,16 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         n_out = weights_in_lds ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds_tail + tail_bytes + 16))   // header word 4, copied behind the tail
                                : hdr_n_out;                                                                                   // (wave tiles: nothing of the network is in LDS)
         n_out = min(n_out, kMaxOut);
+        {
+            // the image's descale section (three words, read one by one: as one 16-byte vector behind a select hipcc 7.2 used word 0 for all three)
+            const int *dsp = reinterpret_cast<const int *>(lds_tail + tail_bytes - 32);
+            const int d1 = weights_in_lds ? dsp[0] : hdr_d1;
+            const int d2 = weights_in_lds ? dsp[1] : hdr_d2;
+            const int d3 = weights_in_lds ? dsp[2] : hdr_d3;
+            ds1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(d1));
+            ds2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(d2));
+            ds3 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(d3));
+        }
         loaded_net = net;
         loaded_slot = cur_slot;
         stamp(a, wave, lane, 1);
@@ -893,11 +893,37 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
+// The three dense layers' power-of-two exponents (their largest |weight| into [2^13, 2^14), policy_pack.h) -> the image's descale
+// section: one workgroup, first in the stream; the pack kernel below reads the exponents from there.
+__global__ void oc_policy_scales_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
+    __shared__ float cs[OC_POLICY_O];
+    __shared__ float red[3][256];
+    const int t = threadIdx.x;
+    if (t < OC_POLICY_O) cs[t] = oc_policy_conv_scale(w, t, L.digits) * oc_pow2f(oc_policy_conv_shift(L.digits));
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    auto upd = [](float &m, float v) { v = v < 0.f ? -v : v; if (v > m && v < 3.0e38f) m = v; };
+    const int per_out = OC_POLICY_O * L.P;
+    for (int i = t; i < OC_POLICY_HID * per_out; i += 256) upd(m1, w.fc1_w[i] * cs[(i % per_out) / L.P]);
+    for (int i = t; i < OC_POLICY_HID * OC_POLICY_HID; i += 256) upd(m2, w.fc2_w[i]);
+    for (int i = t; i < L.n_out * OC_POLICY_HID; i += 256) upd(m3, w.head_w[i]);
+    red[0][t] = m1; red[1][t] = m2; red[2][t] = m3;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (t < d)
+            for (int k = 0; k < 3; ++k) red[k][t] = red[k][t] > red[k][t + d] ? red[k][t] : red[k][t + d];
+        __syncthreads();
+    }
+    if (t < 8) dst[L.off_ds / 4 + t] = oc_policy_pack_ds(oc_policy_scales_from_max(red[0][0], red[1][0], red[2][0]), t);
+}
+
 __global__ void oc_policy_pack_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
-    const long long words = L.total / 4;
+    const long long words = L.total / 4, ds0 = L.off_ds / 4;
+    oc_policy_scales sc;
+    sc.e1 = static_cast<int32_t>(dst[ds0 + 4]); sc.e2 = static_cast<int32_t>(dst[ds0 + 5]); sc.e3 = static_cast<int32_t>(dst[ds0 + 6]);
     for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < words;
          i += static_cast<long long>(gridDim.x) * blockDim.x)
-        dst[i] = oc_policy_pack_word(L, w, i);
+        if (i < ds0 || i >= ds0 + 8) dst[i] = oc_policy_pack_word(L, w, sc, i);     // (the descale section is the scales kernel's)
 }
 
 unsigned long long *g_trace = nullptr;    // device buffer of the diagnostics entry below (stays NULL in the product library)
@@ -938,7 +964,8 @@ int oc_policy_pack_host(const oc_policy_shape *shape, const float *conv_w, const
     if (any_null(w) || !host_dst) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_policy_pack_host: NULL pointer");
     const oc_policy_layout L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
     uint32_t *dst = static_cast<uint32_t *>(host_dst);
-    for (int64_t i = 0; i < L.total / 4; ++i) dst[i] = oc_policy_pack_word(L, w, i);
+    const oc_policy_scales sc = oc_policy_compute_scales(L, w);
+    for (int64_t i = 0; i < L.total / 4; ++i) dst[i] = oc_policy_pack_word(L, w, sc, i);
     return OC_OK;
 }
 
@@ -952,6 +979,7 @@ int oc_policy_pack(const oc_policy_shape *shape, const float *d_conv_w, const fl
     const oc_policy_layout L = oc_policy_make_layout(shape->width, shape->height, shape->digits, shape->n_out);
     const unsigned grid = static_cast<unsigned>((L.total / 4 + 255) / 256);
     const OcDeviceScope on_device(oc_device_of_pointer(d_dst));
+    hipLaunchKernelGGL(oc_policy_scales_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), L, w, static_cast<uint32_t *>(d_dst));
     hipLaunchKernelGGL(oc_policy_pack_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), L, w,
                        static_cast<uint32_t *>(d_dst));
     const hipError_t err = hipGetLastError();
@@ -1201,7 +1229,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
             a.lds_wave_bytes = std::max(a.lds_wave_bytes, (kRowsPerBlock * ((a.slot[i].RB + 15) & ~15) + 1023) / 1024 * 1024);
     }
     constexpr long long kLds = 160 * 1024;
-    const long long w_tail_all = s0.L.off_bh + 32 - s0.L.off_fc1, w_tail_small = s0.L.off_bh + 32 - s0.L.off_b1;
+    const long long w_tail_all = s0.L.off_ds + 32 - s0.L.off_fc1, w_tail_small = s0.L.off_ds + 32 - s0.L.off_b1;
     const long long w_conv = s0.L.off_fc1 - s0.L.off_conv, obs1 = a.lds_wave_bytes;
     // Plan (profiles/r02_policy_plan_sweep.log):
     //   8 wavefronts (two per SIMD, 256 registers each) when eight staging areas fit next to the conv digits and the small
