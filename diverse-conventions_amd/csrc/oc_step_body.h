@@ -119,10 +119,63 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     const int64_t last_chunk = KP_n_kitchens(a) * KP_recq(a) - 1;
     // group -> (batch item, first kitchen of the group inside the item); one item unless BATCH
     auto item_of = [&](int g) { return BATCH ? g / a.batch_groups : 0; };
-    auto first_kitchen = [&](int g, int item) { return static_cast<int64_t>(BATCH ? g - item * a.batch_groups : g) * KP_kpw(a); };
+    // ---- what a group is.  Ordinarily KPW consecutive kitchens, whose tiles -- and hence plane bytes -- are the group's own.
+    // Under OC_XW_SUM (specialised build, one launch per step, one engine) a group is sized for the XCD that runs it: the XCDs do
+    // not stream stores at the same rate -- on equal shares the odd ones end 1-2 us after the even ones and the launch is as long as
+    // the slowest (tools/probes/ticket_atomic.hip; per-XCC end times of tools/trace_phases.py) -- and workgroup b runs on XCD
+    // b mod 8, so group g, taken by a workgroup of XCD g mod 8 whenever the grid is a multiple of eight, *owns* byte (g mod 8) of
+    // OC_XW_PACK kitchens, eight consecutive groups covering OC_XW_SUM.  A wavefront's time follows its own bytes, so the sizes must
+    // move by single kitchens; but a group whose first plane byte is not 64-byte aligned pays a read-modify-write for every partial
+    // 64-byte word of every store instruction (17 / 15 kitchens per group with cramped_room's 400-byte kitchens: 18.5 us against
+    // 11.9).  So ownership of *kitchens* (transition, state, reward, done) and of *plane bytes* are separated: the byte range of a
+    // group runs from tile T(k0) to tile T(k1), T(k) = k*S rounded DOWN to a multiple of 16 tiles = 320 bytes (T(N) = N*S), i.e. the
+    // first tiles of its range may belong to kitchen k0-1 -- the *halo* kitchen, which the group loads and steps as well (the
+    // transition runs one kitchen per lane with most lanes idle: the duplicate costs nothing) without writing its state, reward or
+    // done -- and the last tiles of its own last kitchen are written by the next group.  It still ENCODES through the end of its
+    // last kitchen: phase E is also where lying soups tick in the state.
+    // Correct under any block -> XCD mapping and any grid: a group's kitchens and bytes are a function of its index alone.
+#if defined(OC_XW_SUM)
+    constexpr bool kXW = !FUSED && !BATCH;
+#else
+    constexpr bool kXW = false;
+#endif
+    struct Geom {
+        int64_t k0;          // first kitchen in LDS (the halo kitchen if there is one)
+        int n_lds, halo;     // kitchens in LDS; how many of them (0 / 1), in front, are not the group's own
+        int64_t tile0;       // first tile of the group's byte range, flat index kitchen * S + tile
+        int ntiles, nflush;  // tiles to encode from tile0 on; tiles whose bytes the group writes
+    };
+    auto geom_of = [&](int g, int item) {
+        Geom G;
+        int64_t k0;
+        int nk;
+#if defined(OC_XW_SUM)
+        if (kXW) {
+            k0 = static_cast<int64_t>(g >> 3) * OC_XW_SUM + static_cast<int64_t>((OC_XW_PREFIX >> (8 * (g & 7))) & 0xFFull);
+            nk = static_cast<int>((OC_XW_PACK >> (8 * (g & 7))) & 0xFFull);
+        } else
+#endif
+        {
+            k0 = static_cast<int64_t>(BATCH ? g - item * a.batch_groups : g) * KP_kpw(a);
+            nk = KP_kpw(a);
+        }
+        nk = static_cast<int>(max(static_cast<int64_t>(0), min(static_cast<int64_t>(nk), KP_n_kitchens(a) - k0)));
+        if (kXW && nk > 0) {
+            const int64_t k1 = k0 + nk;
+            const int64_t t_lo = (k0 * S) & ~static_cast<int64_t>(15);
+            const int64_t t_hi = k1 >= KP_n_kitchens(a) ? KP_n_kitchens(a) * S : (k1 * S) & ~static_cast<int64_t>(15);
+            G.halo = t_lo < k0 * S ? 1 : 0;                  // (S >= 16, checked by the host: the halo is one kitchen at most)
+            G.k0 = k0 - G.halo; G.n_lds = nk + G.halo;
+            G.tile0 = t_lo; G.ntiles = static_cast<int>(k1 * S - t_lo); G.nflush = static_cast<int>(t_hi - t_lo);
+        } else {
+            G.halo = 0; G.k0 = k0; G.n_lds = nk;
+            G.tile0 = k0 * S; G.ntiles = G.nflush = nk * S;
+        }
+        return G;
+    };
     auto prefetch = [&](int g) {
         const int item = item_of(g);
-        const int64_t k0 = first_kitchen(g, item);
+        const int64_t k0 = geom_of(g, item).k0;
         const int64_t c0 = k0 * KP_recq(a) + lane;
         const u32x4 *st = reinterpret_cast<const u32x4 *>(a.state + (BATCH ? item * a.state_batch_stride : 0));
 #pragma unroll
@@ -155,7 +208,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     // does not wait for the state.  The loads are unconditional and "landed" through an empty asm: left to itself the compiler sinks
     // each into the `if` of its LDS write -- load, vmcnt(0), write, load, vmcnt(0), write: two round trips, the first of them behind
     // the state loads, in front of everything a wavefront does (seen in the code object of the specialised build).
+#if defined(OC_XCC_ROT) && OC_XCC_ROT
+    int group = (block_id + OC_XCC_ROT) % n_blocks;               // experiment: the groups of XCD x handled by XCD x-1
+#else
     int group = block_id;
+#endif
     {
         const u32x4 *img = reinterpret_cast<const u32x4 *>(a.tabs);
         const int nq4 = lds_table_dwords(S, KP_n_pots(a), KP_n_counters(a)) / 4;
@@ -193,8 +250,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
 
     for (; group < KP_n_groups(a); group += n_blocks) {
         const int item = item_of(group);
-        const int64_t k0 = first_kitchen(group, item);
-        const int n_valid = static_cast<int>(min(static_cast<int64_t>(KP_kpw(a)), KP_n_kitchens(a) - k0));
+        const Geom G = geom_of(group, item);
+        const int64_t k0 = G.k0;                     // first kitchen in LDS
+        const int n_valid = G.n_lds;                 // kitchens in LDS: all of them are stepped, the group's own are written back
+        const int halo = kXW ? G.halo : 0;
         const int nq = n_valid * KP_recq(a);
 
         // ---- prefetched state block -> LDS, then start fetching the next group
@@ -208,8 +267,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
         if (group + n_blocks < KP_n_groups(a)) prefetch(group + n_blocks);   // (wave-uniform; the last group: nothing to fetch)
         wave_sync();
         if (KP_trace(a) && stamp[6] == 0) stamp[6] = __builtin_amdgcn_s_memrealtime();
-        const int64_t plane_base = k0 * S * kChannels;   // byte offset of this group's kitchens in a viewer plane
-        const int ntiles = n_valid * S;
+        const int64_t plane_base = G.tile0 * kChannels;  // byte offset of this group's first tile in a viewer plane
+        const int ntiles = G.ntiles, nflush = G.nflush;
         const int npass = (ntiles + tpp - 1) / tpp;
 
         // FUSED: the whole rollout of this group happens here, its state never leaves LDS between steps
@@ -282,9 +341,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                     posor = pos0 | (or0 << 8) | (pos1 << 16) | (static_cast<uint32_t>(or1) << 24);
                     if (is_done) { posor = KP_start_posor(a); h0 = 0; h1 = 0; ts = 0; }
                     rec[S] = posor; rec[S + 1] = h0; rec[S + 2] = h1; rec[S + 3] = static_cast<uint32_t>(ts);
-                    reward_t[kid] = rew;                     // envs/overcooked2_env.py:336-339: sum, to every player
-                    reward_t[KP_n_kitchens(a) + kid] = rew;
-                    done_t[kid] = static_cast<int32_t>(is_done);
+                    if (lane >= halo) {                      // (a halo kitchen's outputs are its owner's)
+                        reward_t[kid] = rew;                 // envs/overcooked2_env.py:336-339: sum, to every player
+                        reward_t[KP_n_kitchens(a) + kid] = rew;
+                        done_t[kid] = static_cast<int32_t>(is_done);
+                    }
                 }
                 // per-kitchen values every tile lane of phase E needs, computed once here
                 uint32_t *kd = L.kd + lane * kKd;
@@ -299,6 +360,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
 
             // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
             int k = k_first, o = o_first;
+            if (kXW) {                                       // the byte range starts tile0 - k0*S tiles into the LDS kitchens
+                const int f = static_cast<int>(G.tile0 - k0 * S) + lane;
+                k = f / S; o = f - k * S;
+            }
             // One tile of phase E is split in two so that two tiles per lane can be in flight: all LDS
             // reads of both tiles are issued before either tile's arithmetic (the kernel runs at 1-2 waves
             // per SIMD, so instruction-level parallelism inside the wave is what hides LDS latency).
@@ -346,8 +411,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 k += dk; o += dq;
                 if (o >= S) { o -= S; ++k; }
             };
-            auto encode_passes = [&](int p0) {
-                const int pend = min(p0 + KP_gpasses(a), npass);
+            auto encode_passes = [&](int p0, int count) {
+                const int pend = min(p0 + count, npass);
                 if (KP_ablate(a) & 4) return;
                 int p = p0;
                 for (; p + 1 < pend; p += 2) {               // two tiles per lane in flight
@@ -365,9 +430,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                     tile_encode(r0, ((p - p0) * tpp + lane) * kTileDwords);
                 }
             };
-            auto flush_passes = [&](int p0) {
+            auto flush_passes = [&](int p0, int count) {
                 // ---- flush the staged tiles of both viewers: contiguous bytes in the output planes
-                const int gbytes = (min(ntiles - p0 * tpp, KP_gpasses(a) * tpp)) * kChannels;
+                const int gbytes = max(0, min(nflush - p0 * tpp, count * tpp)) * kChannels;
                 const int64_t goff = plane_base + static_cast<int64_t>(p0) * tpp * kChannels;
 #if defined(OC_JIT) && ((defined(OC_FAST_FLUSH) && OC_FAST_FLUSH) || (!defined(OC_FAST_FLUSH) && OC_S <= 32))
                 // Specialised build, full flush group (every one but a ragged last): the chunk count is a constant, so all LDS
@@ -419,19 +484,24 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
             };
             // first flush group peeled so that the prefetch lands at a fixed program point: after the first
             // tiles are encoded (latency cover) and before this group's first plane store is issued
-            encode_passes(0);
+#if defined(OC_FIRST_PASSES) && OC_FIRST_PASSES > 0
+            const int first_passes = min(OC_FIRST_PASSES, KP_gpasses(a));     // experiment: a shorter first flush group, stores start earlier
+#else
+            const int first_passes = KP_gpasses(a);
+#endif
+            encode_passes(0, first_passes);
             wave_sync();
             if (!FUSED || step == 0) land_prefetch();
-            flush_passes(0);
+            flush_passes(0, first_passes);
             wave_sync();
             if (KP_trace(a) && stamp[3] == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
 #if defined(OC_NOUNROLL) && OC_NOUNROLL
 #pragma unroll 1
 #endif
-            for (int p0 = KP_gpasses(a); p0 < npass; p0 += KP_gpasses(a)) {
-                encode_passes(p0);
+            for (int p0 = first_passes; p0 < npass; p0 += KP_gpasses(a)) {
+                encode_passes(p0, KP_gpasses(a));
                 wave_sync();
-                flush_passes(p0);
+                flush_passes(p0, KP_gpasses(a));
                 wave_sync();
             }
             // ---- trajectory recording: the post-step records to the caller's slot, in the launch that computed them (the next
@@ -441,7 +511,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 uint4 *rdst = a.rec_out + (FUSED ? step * a.rec_step_stride : 0) + k0 * KP_recq(a);
 #pragma unroll
                 for (int q = 0; q < QN; ++q)
-                    if (lane + q * kWave < nq) {
+                    if (lane + q * kWave < nq && lane + q * kWave >= halo * KP_recq(a)) {
                         const uint32_t *sp = L.state + loff[q];
                         store16<SM>(reinterpret_cast<int8_t *>(rdst + lane + q * kWave), make_uint4(sp[0], sp[1], sp[2], sp[3]));
                     }
@@ -455,7 +525,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
             uint4 *dst = a.state + k0 * KP_recq(a);
 #pragma unroll
             for (int q = 0; q < QN; ++q)
-                if (lane + q * kWave < nq) {
+                if (lane + q * kWave < nq && lane + q * kWave >= halo * KP_recq(a)) {
                     const uint32_t *sp = L.state + loff[q];
                     // plain stores: the records are re-read by the next launch, and sending them write-through as well
                     // measured slower (12.9 vs 12.2 us at 65 536 kitchens)

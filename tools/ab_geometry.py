@@ -20,6 +20,10 @@ for cand in cands:
         os.environ["OC_FAST_FLUSH"] = str(cand[3])
     else:
         os.environ.pop("OC_FAST_FLUSH", None)
+    if len(cand) > 4:                                     # 5th field: passes of the first flush group (0: as the others)
+        os.environ["OC_FIRST_PASSES"] = str(cand[4])
+    else:
+        os.environ.pop("OC_FIRST_PASSES", None)
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(kpw, gp, wpc)
     e.rollout(acts, 100)

@@ -24,6 +24,14 @@ for cand in cands:
         os.environ["OC_STORE_MODE"] = f"2,{cand[4]}"
     else:
         os.environ.pop("OC_STORE_MODE", None)
+    if len(cand) > 5:                                     # sixth field: passes of the FIRST flush group (0: as the others)
+        os.environ["OC_FIRST_PASSES"] = str(cand[5])
+    else:
+        os.environ.pop("OC_FIRST_PASSES", None)
+    if len(cand) > 7:                                     # seventh, eighth field: kitchens per group on even / odd XCDs (0,0: equal groups)
+        os.environ["OC_XCC_WEIGHTS"] = ",".join(str(cand[6 + (x & 1)]) for x in range(8)) if cand[6] else ""
+    elif "OC_XCC_WEIGHTS" in os.environ and not os.environ.get("OC_XCC_WEIGHTS_KEEP"):
+        os.environ.pop("OC_XCC_WEIGHTS")
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(*cand[:3])
     engines.append(e)

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Policy kernel (oc_policy_forward) on every classic layout: the launch alone (4 actors + 4 critics, both sides) and the
 whole policies-in-the-loop step of config 4's per-GPU share.  The bound printed is the MFMA issue time of the launch:
-per 32 rows P x (6 x digits + 24) + 48 + 24 matrix instructions of 32 cycles each on one SIMD (i8 conv digits + bf16
-piece products of the dense layers), at 2.4 GHz and at the ~2.1 GHz the chip holds under this load.
+per 32 rows P x (6 x digits + 12) + 24 + 12 matrix instructions of 32 cycles each on one SIMD (i8 conv digits + f16
+two-piece products of the dense layers), at 2.4 GHz and at the ~2.1 GHz the chip holds under this load.
 Round-2 history: the same script compared the removed two-wavefront plans (profiles/r02_policy_pair_split.log,
 r02_policy_conv_dense_split.log; f32 dense layers then, 23 040 cycles per 32 rows on cramped_room against 11 520 now)."""
 import json, os, sys, time
+if os.environ.get("OC_POLICY_PLAN"):
+    os.environ.setdefault("OC_DIAGNOSTICS", "1")      # the plan override is a knob of the diagnostics build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench_paired_rollout import random_actor, random_critic, run_fused
@@ -42,12 +44,12 @@ for layout, n in (("cramped_room", 61440), ("asymmetric_advantages", 30720), ("c
         torch.cuda.synchronize()
         us = min(us, e0.elapsed_time(e1) * 1e3 / 30)
     evals = 2 * rows
-    cycles = evals / 32 * 32 * (P * (6 * DIGITS + 24) + 48 + 24)
+    cycles = evals / 32 * 32 * (P * (6 * DIGITS + 12) + 24 + 12)
     bound24 = cycles / 1024 / 2400.0
     print(json.dumps({"plan": plan, "layout": layout, "evaluations": evals, "us": round(us, 1), "issue_bound_us_at_2.4GHz": round(bound24, 1),
                       "frac_of_bound_2.4GHz": round(bound24 / us, 3), "frac_at_2.1GHz": round(bound24 * 2.4 / 2.1 / us, 3)}), flush=True)
 # BASELINE config 4 with the policies in the loop (asymmetric_advantages, 16 conventions in 31 pairing segments, critics): one GPU's share
 # of the 65 536 kitchens on 8, 4, 2 GPUs and the whole batch on one -- the strong-scaling prediction of DESIGN.md section 7
-for gpus in (8, 4, 2, 1):
+for gpus in ((8, 4, 2, 1) if not os.environ.get("OC_SKIP_SHARES") else ()):
     r = run_fused("asymmetric_advantages", (65536 // gpus) // 31, 15, critics=True)
     print(json.dumps({"plan": plan, "config4_share": r, "of_gpus": gpus}), flush=True)

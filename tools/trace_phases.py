@@ -19,16 +19,29 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 kpw = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 g = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 w = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+fresh = len(sys.argv) > 6 and sys.argv[6] == "fresh"      # trace a step into a time-major slot (destination != the previous step's)
 params = get_base_layout_params(layout, 200)
 eng = OvercookedEngine(params, n, 0)
 eng.set_tuning(kpw, g, w)
 actions = torch.randint(0, 6, (8, 2, n), device="cuda", dtype=torch.int32)
-eng.rollout(actions, 20)
+slots = None
+if fresh:
+    W, H = params["width"], params["height"]
+    slots = (torch.zeros((64, 2, n, W, H, 20), dtype=torch.int8, device="cuda"), torch.zeros((64, 2, n), dtype=torch.int32, device="cuda"),
+             torch.zeros((64, n), dtype=torch.int32, device="cuda"))
+    eng.rollout(actions, 64, obs=slots[0], reward=slots[1], done=slots[2])
+    if kpw == 0:
+        kpw, g, w = 16, 4, 8                           # the engine's own geometry for fresh destinations at this size (set_tuning(0,0,0) keeps it)
+eng.rollout(actions, 20) if not fresh else None
 torch.cuda.synchronize()
 L = native.lib()
 L.oc_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
 native.check(L.oc_debug_trace(eng._handle, 1, None, 0))
-eng.step(actions[0])
+if fresh:
+    eng.rollout(actions, 7, obs=slots[0][:7], reward=slots[1][:7], done=slots[2][:7])     # the traced launch follows launches of its own kind
+    eng.step(actions[0], obs=slots[0][7], reward=slots[1][7], done=slots[2][7])
+else:
+    eng.step(actions[0])
 nw = min((n + kpw - 1) // kpw, w * 256)
 buf = np.zeros((nw, 16), dtype=np.uint64)
 native.check(L.oc_debug_trace(eng._handle, 0, buf.ctypes.data_as(ctypes.c_void_p), nw))
