@@ -72,16 +72,18 @@ int oc_gather_records(const void *d_packed, int64_t src_rows, int32_t n_cols, vo
  * train/MAPPO/r_actor_critic.py:57-76,175-199) for the reference architecture: CNNBase (utils/cnn.py:12-60: conv 3x3
  * valid 20 -> hidden/2, ReLU, flatten, Linear -> hidden, ReLU, Linear -> hidden, ReLU) + one Linear head
  * (6 action logits, utils/act.py + distributions.py:60-80, or 1 value, `v_out`).  hidden_size 64 (train_xp.sh:12);
- * other sizes return OC_ERR_UNSUPPORTED.  Numerics: conv in exact integer arithmetic on `digits` base-128
- * fixed-point weight digits (4: quantisation 2^-28 of each channel's largest weight; the channel's bias rides in the
- * same units), dense layers as f32 x f32 products on the bf16 matrix pipe (both operands split exactly into three bf16
- * pieces, six piece products each, f32 accumulate: what is dropped is below 2^-23 of a product); outputs agree with
- * the reference's f32 forward to ~1e-6 of their magnitude (tools/policy_accuracy.py measures it against float64). */
+ * other sizes return OC_ERR_UNSUPPORTED.  Numerics: conv in exact integer arithmetic on `digits` base-256
+ * fixed-point weight digits (3, the default: quantisation 2^-24 of each channel's largest weight; the channel's bias
+ * rides in the same units), dense layers as f32 x f32 products on the f16 matrix pipe: both operands as two f16 pieces
+ * hi = f16(x), lo = f16(x - hi) (round to nearest; weights up-scaled per layer by a power of two, activations fed at
+ * 2^4 and clamped at 65504 by the ReLU), three piece products hi hi + hi lo + lo hi, f32 accumulate: what is dropped is
+ * below 2^-22 of a product; outputs agree with the reference's f32 forward to ~1e-6 of their magnitude
+ * (tools/policy_accuracy.py measures it against float64: no worse than a plain f32 evaluation). */
 typedef struct {
     int32_t width, height;     /* observation grid; rows are width*height*20 int8, C fastest, W before H */
     int32_t hidden;            /* reference --hidden_size: 64 */
     int32_t n_out;             /* head outputs of the network being packed: 1..8 (6 logits / 1 value) */
-    int32_t digits;            /* conv weight digits 1..4 (7, 14, 21, 28 bits) */
+    int32_t digits;            /* conv weight digits 1..4 (8, 16, 24, 32 bits; 3 is the default of the Python host) */
 } oc_policy_shape;
 
 #define OC_POLICY_TILE_ACT 1   /* tile flag: actor epilogue (log-softmax, action draw); otherwise raw head outputs */

@@ -589,3 +589,20 @@ def test_this_whole_file_on_the_generic_ahead_of_time_kernel(clean_launcher):
                            env={"OC_NO_JIT": "1"}, timeout=1100)
     tail = r["stdout"][-1500:] + r["stderr"][-500:]
     assert r["rc"] == 0 and " passed" in r["stdout"] and "failed" not in r["stdout"], tail
+
+
+def test_per_xcd_group_sizes_with_a_halo_kitchen_on_the_diagnostics_build(clean_launcher):
+    """The experiment of round 4: groups sized per XCD, kitchen by kitchen, their plane bytes cut at multiples of
+    16 tiles with the neighbour's last kitchen stepped as a halo (oc_step_body.h, OC_XW_SUM).  Not a product path -- it gained nothing --
+    but it shares the body's group geometry with every kernel, so its parity is kept: every kitchen of a ragged batch against the oracle,
+    in place and into time-major slots with records, group sizes that include 0 and 1 (tools/check_xcc_weights.py, csrc/liboc_hip_diag.so)."""
+    import os
+    import sys
+    from diverse_conventions_amd import native
+    diag = os.path.join(native.CSRC, "liboc_hip_diag.so")
+    newest = max(os.path.getmtime(os.path.join(native.CSRC, f)) for f in os.listdir(native.CSRC) if f.endswith((".hip", ".h")))
+    if not os.path.exists(diag) or os.path.getmtime(diag) < newest:
+        pytest.skip("csrc/liboc_hip_diag.so is not built for these sources (OC_DIAGNOSTICS=1 python -c 'from diverse_conventions_amd import native; native.build()')")
+    for argv in (["cramped_room", "8191", "24", "19,13,17,15,16,0,23,1"], ["coordination_ring", "6001", "20", "17,15,17,15,17,15,17,15"]):
+        r = clean_launcher.run([sys.executable, "tools/check_xcc_weights.py"] + argv, env={"OC_DIAGNOSTICS": "1"}, timeout=600)
+        assert r["rc"] == 0 and "bit-exact" in r["stdout"], r["stdout"][-1500:] + r["stderr"][-800:]

@@ -18,11 +18,25 @@ g = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 w = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 params = get_base_layout_params(layout, 200)
 actions = torch.randint(0, 6, (64, 2, n), device="cuda", dtype=torch.int32)
+fresh = len(sys.argv) > 6 and sys.argv[6] == "fresh"       # step into time-major slots instead of in place
+W, H = params["width"], params["height"]
+slots = (torch.zeros((64, 2, n, W, H, 20), dtype=torch.int8, device="cuda"), torch.zeros((64, 2, n), dtype=torch.int32, device="cuda"),
+         torch.zeros((64, n), dtype=torch.int32, device="cuda")) if fresh else None
 for ab in (0, 1, 2, 4, 8, 16, 6, 7, 1 | 4, 2 | 8, 31, 31 - 2, 31 - 4):
     os.environ["OC_ABLATE"] = str(ab)
     eng = OvercookedEngine(params, n, 0)
-    eng.set_tuning(kpw, g, w)
-    eng.rollout(actions, 50)
-    us = min(eng.rollout_timed(actions, 300) for _ in range(3)) * 1e3 / 300
+    if kpw:
+        eng.set_tuning(kpw, g, w)
+    if fresh:
+        import time
+        eng.rollout(actions, 64, obs=slots[0], reward=slots[1], done=slots[2]); torch.cuda.synchronize()
+        us = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(5): eng.rollout(actions, 64, obs=slots[0], reward=slots[1], done=slots[2])
+            torch.cuda.synchronize(); us = min(us, (time.perf_counter() - t0) / 320 * 1e6)
+    else:
+        eng.rollout(actions, 50)
+        us = min(eng.rollout_timed(actions, 300) for _ in range(3)) * 1e3 / 300
     print(f"ablate={ab:2d} ({ab:05b})  {us:7.2f} us/launch", flush=True)
     eng.close()

@@ -15,7 +15,7 @@ from bench_fused_policy import random_net
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 4)
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 245760
 rpt = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
-digits = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+digits = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 gen = torch.Generator().manual_seed(0)
 nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_net(W, H, 6, ACTOR_HEAD, gen) for _ in range(4)], digits=digits)
 obs = (torch.rand((rows, W, H, 20), device="cuda") < 0.1).to(torch.int8)
