@@ -403,10 +403,12 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
         }
     };
     long long total = 0;
+    int nb0 = 0, incl0 = 0;                                           // the first 64 entries' counts, kept for the second pass: one round trip less
     if (!a.tile_per_wg)
         for (int c = 0; c < a.n_tiles; c += 64) {
             int nb, incl;
             scan64(c, nb, incl);
+            if (c == 0) { nb0 = nb; incl0 = incl; }
             total += __builtin_amdgcn_readlane(incl, 63);
         }
     wg0 = a.tile_per_wg ? 0 : total * blockIdx.x / gridDim.x;
@@ -424,8 +426,8 @@ __device__ __forceinline__ bool policy_find_stretch(const PolicyArgs &a, int lan
     if (wg0 >= wg1) return false;
     if (!a.tile_per_wg)
         for (int c = 0; c < a.n_tiles; c += 64) {
-            int nb, incl;
-            scan64(c, nb, incl);
+            int nb = nb0, incl = incl0;
+            if (c) scan64(c, nb, incl);
             const long long target = wg0 - tstart;
             const unsigned long long hit = __ballot(static_cast<long long>(incl - nb) <= target && target < incl);
             if (hit) {

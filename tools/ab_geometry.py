@@ -24,6 +24,10 @@ for cand in cands:
         os.environ["OC_FIRST_PASSES"] = str(cand[4])
     else:
         os.environ.pop("OC_FIRST_PASSES", None)
+    if len(cand) > 5:                                     # 6th field: wavefronts per workgroup (1, 2, 4, 8)
+        os.environ["OC_WG_WAVES"] = str(cand[5])
+    else:
+        os.environ.pop("OC_WG_WAVES", None)
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(kpw, gp, wpc)
     e.rollout(acts, 100)
