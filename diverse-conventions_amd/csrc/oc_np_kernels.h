@@ -144,6 +144,9 @@ __global__ void np_step_kernel(const NpArgs a) {
 // viewer, only the player slots differ (ref:221-234) -- into one staging range per viewer, and the block writes the P contiguous
 // byte ranges out 16 bytes per lane.  (The first version ran one viewer per block straight from global memory: ~11 scattered
 // dword loads per thread and viewer, 168 us for 4 x 65 536 kitchens of multiplayer_schelling against 400 MB of planes.)
+#ifndef OC_NP_SM
+#define OC_NP_SM SM_PLAIN      // store mode of the plane stores (store16)
+#endif
 constexpr int kNpThreads = 256;
 constexpr int kNpMaxC = 5 * kMaxP + 10;             // 30 bytes per tile with four players
 
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
         int done_bytes = 0;
         if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
             const int n16 = nbytes >> 4;
-            for (int i = threadIdx.x; i < n16; i += kNpThreads) store16<SM_PLAIN>(dst + 16 * i, reinterpret_cast<const uint4 *>(src)[i]);
+            for (int i = threadIdx.x; i < n16; i += kNpThreads) store16<OC_NP_SM>(dst + 16 * i, reinterpret_cast<const uint4 *>(src)[i]);
             done_bytes = n16 << 4;
         }
         for (int i = done_bytes + threadIdx.x; i < nbytes; i += kNpThreads) dst[i] = src[i];
