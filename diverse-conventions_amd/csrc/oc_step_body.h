@@ -415,6 +415,23 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 const int pend = min(p0 + count, npass);
                 if (KP_ablate(a) & 4) return;
                 int p = p0;
+#if defined(OC_ENCODE_ILP4) && OC_ENCODE_ILP4
+                for (; p + 3 < pend; p += 4) {               // four tiles per lane in flight: what phase E waits for are its LDS round trips
+                    const int slot = ((p - p0) * tpp + lane) * kTileDwords;
+                    const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);
+                    advance();
+                    const TileIn r1 = tile_read(k, o, lane < tpp && (p + 1) * tpp + lane < ntiles);
+                    advance();
+                    const TileIn r2 = tile_read(k, o, lane < tpp && (p + 2) * tpp + lane < ntiles);
+                    advance();
+                    const TileIn r3 = tile_read(k, o, lane < tpp && (p + 3) * tpp + lane < ntiles);
+                    advance();
+                    tile_encode(r0, slot);
+                    tile_encode(r1, slot + tpp * kTileDwords);
+                    tile_encode(r2, slot + 2 * tpp * kTileDwords);
+                    tile_encode(r3, slot + 3 * tpp * kTileDwords);
+                }
+#endif
                 for (; p + 1 < pend; p += 2) {               // two tiles per lane in flight
                     const int slot = ((p - p0) * tpp + lane) * kTileDwords;
                     const TileIn r0 = tile_read(k, o, lane < tpp && p * tpp + lane < ntiles);

@@ -28,6 +28,10 @@ for cand in cands:
         os.environ["OC_WG_WAVES"] = str(cand[5])
     else:
         os.environ.pop("OC_WG_WAVES", None)
+    if len(cand) > 6:                                     # 7th field: OC_ENCODE_ILP4 (experiment)
+        os.environ["OC_ENCODE_ILP4"] = str(cand[6])
+    else:
+        os.environ.pop("OC_ENCODE_ILP4", None)
     e = OvercookedEngine(params, n, 0)
     e.set_tuning(kpw, gp, wpc)
     e.rollout(acts, 100)
