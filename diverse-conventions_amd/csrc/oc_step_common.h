@@ -47,7 +47,7 @@ namespace oc_dev {
 #define KP_delta_pack(a) (OC_DELTA_PACK)
 #define KP_n_kitchens(a) ((a).n_kitchens)
 #if defined(OC_JIT_ABLATE)
-#define KP_ablate(a) (OC_JIT_ABLATE)       // diagnostics build: OC_ABLATE at the time the module is built
+#define KP_ablate(a) (OC_JIT_ABLATE)       // diagnostics build: the phase-skipping bits at the time the module is built
 #else
 #define KP_ablate(a) (0)
 #endif

@@ -296,8 +296,11 @@
             }
             continue;
         }
-        // actor: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80), then argmax (mode) or
-        // a Gumbel-max draw
+        // actor: log-softmax (Categorical(logits=).logits, reference distributions.py:60-80), then argmax (mode) or a draw
+        // (Categorical.sample(), distributions.py:20-25) by inverse CDF: ONE uniform per row from the counter hash, the action is the
+        // first whose cumulative mass exceeds u x total.  (Rounds 1-3 drew by Gumbel-max: six hashes and twelve logarithms per row --
+        // quarter-rate multiplies and transcendentals on a vector pipe that is this kernel's binding resource; the launch with
+        // sampled actions took 1.3-1.4 us longer than with argmax)
         // (branch-free over the lane's four outputs: the ones past n_out count as -inf -- exp gives 0, the key never wins -- so
         // the lane halves, which own different numbers of valid outputs, run one straight instruction stream)
         float x[4];
@@ -305,33 +308,44 @@
         for (int r = 0; r < 4; ++r) x[r] = 4 * h + r < n_out ? out[r] : -INFINITY;
         float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+        float ex[4], own = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sum += __expf(x[r] - mx);          // v_exp_f32: relative error ~1e-7 on arguments <= 0
-        sum += __shfl_xor(sum, 32);
+        for (int r = 0; r < 4; ++r) { ex[r] = __expf(x[r] - mx); own += ex[r]; }   // v_exp_f32: relative error ~1e-7 on arguments <= 0
+        const float other = __shfl_xor(own, 32);
+        const float sum = own + other;                                // (the same value in both halves: the addition commutes)
         const float lse = mx + __logf(sum);                          // sum in [1, n_out]: absolute error ~2e-7
-        int best = 0;
-        float best_key = -INFINITY, best_lp = 0.f;
         float lps[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * h + r;
-            const float lp = x[r] - lse;
-            float key = lp;
-            if (a.sample) {                                           // the noise needs no more than the fast logarithm
-                const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), i));
-                key = lp - __logf(-__logf(u));
-            }
-            const bool wins = key > best_key;
-            best_key = wins ? key : best_key; best = wins ? i : best; best_lp = wins ? lp : best_lp;
-            lps[r] = lp;
-        }
+        for (int r = 0; r < 4; ++r) lps[r] = x[r] - lse;
         if (valid && S.logp) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (4 * h + r < n_out) S.logp[row * n_out + 4 * h + r] = lps[r];
         }
-        {
+        int best = 0;
+        float best_lp = 0.f;
+        if (a.sample) {
+            // cumulative masses of this half's actions (half 1 starts behind half 0's); an action past n_out adds nothing and its
+            // cumulative value is the total, which u x total stays below (u < 1) -- rounding up to it is caught by the clamp
+            const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), 0));
+            const float thr = u * sum;
+            float c = h ? other : 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { c += ex[r]; cnt += c <= thr ? 1 : 0; }
+            best = min(cnt + __shfl_xor(cnt, 32), n_out - 1);
+            const int local = best - 4 * h;
+            float lp_sel = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lp_sel = local == r ? lps[r] : lp_sel;
+            best_lp = lp_sel + __shfl_xor(lp_sel, 32);               // (the other half contributes 0)
+        } else {
+            float best_key = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool wins = lps[r] > best_key;
+                best_key = wins ? lps[r] : best_key; best = wins ? 4 * h + r : best; best_lp = wins ? lps[r] : best_lp;
+            }
             const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
             const int obest = __shfl_xor(best, 32);
             if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }

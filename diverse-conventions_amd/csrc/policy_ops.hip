@@ -112,7 +112,7 @@ struct PolicyArgs {
     int coop;                           // a stretch's last one or two blocks are shared by four (two) wavefronts, see "cooperative blocks" in oc_policy_kernel
     uint32_t counter;
     const uint32_t *counter_ptr;        // device counter added to `counter` (graph replay: a new draw per replay), or NULL
-    int sample;                         // 0: argmax, 1: Gumbel-max draw
+    int sample;                         // 0: argmax, 1: a draw from the distribution (inverse CDF of one counter-hash uniform per row)
     int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL

@@ -330,8 +330,9 @@ OC_HD inline uint32_t oc_policy_pack_word(const oc_policy_layout &L, const oc_po
     return cv.u;
 }
 
-// Uniform in (0, 1) for the Gumbel-max action draw: a pure function of (seed, counter, row, action), so a test
-// can re-derive every sampled action from the returned log-probabilities.
+// Uniform in (0, 1) for the action draw: a pure function of (seed, counter, row, a), so a test can re-derive every sampled action
+// from the returned log-probabilities.  The kernel draws by inverse CDF with the ONE uniform of a = 0 per row (rounds 1-3: Gumbel-max
+// over the uniforms of a = 0..5).
 OC_HD inline uint32_t oc_policy_hash(uint32_t seed, uint32_t counter, uint32_t row, uint32_t a) {
     uint32_t x = seed ^ (counter * 0x9E3779B1u) ^ (row * 0x85EBCA77u) ^ (a * 0xC2B2AE3Du);
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;

@@ -338,9 +338,13 @@ class GatherPlan:
             0 if deterministic else 1, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, _ptr(device_counter), _stream(nets.device)))
 
 
-def gumbel_uniform(seed, counter, row, action):
-    """The uniform the kernel used for (row, action) of a draw: lets a test re-derive every sampled action."""
+def draw_uniform(seed, counter, row, action=0):
+    """The counter-hash uniform of (seed, counter, row, action).  The kernel draws a row's action by inverse CDF from the uniform of
+    action 0 (the first action whose cumulative probability exceeds it): lets a test re-derive every sampled action."""
     return float(native.lib().oc_policy_uniform(int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, int(row), int(action)))
+
+
+gumbel_uniform = draw_uniform          # (the name of rounds 1-3, when the draw was Gumbel-max over six uniforms per row)
 
 
 class FusedVectorAgent:

@@ -91,7 +91,7 @@ class MixedPlayRollout:
                 tiles.append((side, choice, critic, 0))
         self.plan = GatherPlan(nets, 2 * n, n, tiles)
         self.ego_id, self.seed, self.deterministic, self.generator = ego_id, seed, deterministic, generator
-        # running draw counter: the kernel's Gumbel noise is hash(seed, counter + t, row, action), so every collection
+        # running draw counter: the kernel's draw uses hash(seed, counter + t, row, 0), so every collection
         # must start where the previous one stopped or it would replay the same noise (as FusedPairedRollout.steps_done does)
         self.draws_done = 0
         T, dev = 2 * self.L, engine.device

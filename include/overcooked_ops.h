@@ -115,7 +115,8 @@ int64_t oc_policy_plan_tiles(const int64_t *seg_row0, const int64_t *seg_rows, c
  * d_obs int8 [n_rows][W][H][20], d_tiles int32 [n_tiles][4] on the device.  Tiles without OC_POLICY_TILE_ACT write
  * d_raw[row * n_out + a] (raw head outputs: critic values, or logits); tiles with it write d_actions[row] (int32),
  * d_action_logp[row] and, if non-NULL, d_logp[row * n_out + a] (normalised log-probabilities).  sample_mode 0 =
- * argmax (FixedCategorical.mode), 1 = Gumbel-max draw with u = oc_policy_uniform(seed, counter + *d_counter, row, a);
+ * argmax (FixedCategorical.mode), 1 = a draw from the distribution (FixedCategorical.sample) by inverse CDF: the first action whose
+ * cumulative probability exceeds u = oc_policy_uniform(seed, counter + *d_counter, row, 0) (rounds 1-3: Gumbel-max over six uniforms);
  * d_counter (device uint32, may be NULL = 0) lets a captured HIP graph draw fresh actions on every replay.
  * d_row_select (int32 [n_rows], may be NULL): per-row policy mixing -- tiles flagged OC_POLICY_TILE_SELECT(v) write only
  * the rows whose entry equals v, so two networks laid over the same rows fill one output buffer between them (the

@@ -425,16 +425,19 @@ def test_device_packer_equals_host_packer():
 
 
 @pytest.mark.gpu
-def test_sampling_is_gumbel_max_of_the_exported_uniforms():
+def test_sampling_is_the_inverse_cdf_of_the_exported_uniform():
+    """A sampled action is the first whose cumulative probability exceeds the row's uniform hash(seed, counter, row, 0)
+    (Categorical.sample() of the reference, train/MAPPO/utils/distributions.py:20-25, with a reproducible uniform)."""
     z, get = cases()
     obs = torch.from_numpy(z["obs"]).cuda()
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get("a0.")])
     r = _run(nets, 240, [(0, 240, 0, TILE_ACT)], obs, seed=1234, counter=9)
-    u = np.array([[gumbel_uniform(1234, 9, row, a) for a in range(6)] for row in range(240)], dtype=np.float32)
-    key = r["logp"] - np.log(-np.log(u))
-    top2 = np.sort(key, axis=-1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 1e-4                      # away from float ties the draw is reproducible
-    assert clear.sum() > 230 and np.array_equal(r["actions"][clear], key.argmax(-1)[clear])
+    u = np.array([gumbel_uniform(1234, 9, row, 0) for row in range(240)], dtype=np.float64)
+    cum = np.cumsum(np.exp(r["logp"].astype(np.float64)), axis=-1)
+    cum /= cum[:, -1:]
+    expect = np.minimum((cum <= u[:, None]).sum(-1), 5)
+    clear = np.abs(cum - u[:, None]).min(-1) > 1e-5               # away from a boundary the draw is reproducible
+    assert clear.sum() > 230 and np.array_equal(r["actions"][clear], expect[clear])
     assert np.allclose(r["action_logp"], np.take_along_axis(r["logp"], r["actions"][:, None].astype(np.int64), 1)[:, 0])
     # different counters give different draws; the empirical law follows the probabilities
     big = obs[:1].expand(20000, 5, 4, 20).contiguous()
