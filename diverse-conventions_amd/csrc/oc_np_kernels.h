@@ -50,6 +50,11 @@ __device__ __forceinline__ int np_count(uint32_t o) { return static_cast<int>(((
 // kitchens -- the index arithmetic of the copy loops and two barriers cost more than the scattered dword accesses, which L2 serves.
 // Round 3 tried it once more per wavefront -- 64 kitchens' records as one flat 16-byte-per-lane copy at an odd LDS stride, no barrier:
 // 107.5-108.0 against 108.3-109.0 us, i.e. nothing: this kernel's time is not in its record accesses.)
+// (Round 4 folded this kernel into the encode kernel -- each block stepping its own four kitchens on the records it holds in LDS anyway,
+// one launch per step: bit-exact and TWICE as slow, 218.8 against 108.8 us at 4 x 65 536 kitchens, 155.8 against 84.9 with three
+// players.  The transition is a serial chain per kitchen; here 65 536 of them overlap each other, there four threads of a block run it
+// while 252 wait, and LDS lets only five blocks share a CU.  Of the step's 101 us of kernel time the encode launch is 79 us at
+// 6.4 TB/s of plane stores and this launch 21.6 us, so what is left for this path is the launch boundary, not the bytes.)
 __global__ void np_step_kernel(const NpArgs a) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= a.n) return;
