@@ -21,6 +21,8 @@ def run(layout, threads, k, critics, T=200):
     crit = [random_critic(W, H, gen) for _ in range(G)] if critics else []
     nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=actors, critics=crit)
     eng = OvercookedEngine(params, threads * G, 0)
+    if os.environ.get("OC_EXP_TUNING"):                    # "kpw,passes,wpc": the env kernel's geometry for every destination kind
+        eng.set_tuning(*[int(v) for v in os.environ["OC_EXP_TUNING"].split(",")])
     ro = FusedPairedRollout(eng, nets, threads, k, critic_nets=[[k + 1 + g for g in range(G)]] * 2 if critics else None)
     ro.step(20); torch.cuda.synchronize()
     t0 = time.perf_counter(); ro.step(T); torch.cuda.synchronize()

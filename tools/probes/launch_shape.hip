@@ -36,5 +36,14 @@ int main() {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("%s %4d x %4d: %.2f us per launch\n", kind == 0 ? "empty" : kind == 1 ? "1 KB in + out per wave" : "empty, 14 KB LDS per wave", sh[0], sh[1], ms);
         }
+    // how the cost of an empty launch grows with its wavefronts (one-wavefront workgroups)
+    for (int waves : {8, 256, 512, 1024, 2048, 4096, 8192}) {
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k_empty, dim3(waves), dim3(64), 0, 0, p);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 1000; ++i) hipLaunchKernelGGL(k_empty, dim3(waves), dim3(64), 0, 0, p);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("empty %5d x   64: %.2f us per launch\n", waves, ms);
+    }
     return 0;
 }
