@@ -1482,7 +1482,9 @@ int oc_policy_rollout(oc_engine *e, const oc_policy_shape *shape, const void *d_
         int32_t *cnt = nullptr, *expd = nullptr, groups = 0;
         const oc_dev::StepArgs *tmpl = nullptr;
         oc_dev::StepArgs probe;
-        if (want && T > 0 && shape->digits == 3 && !d_row_select && !d_records && n_tiles > 0 &&
+        // (not in place with critics: a group is stepped as soon as its ACTOR blocks have arrived, and a critic block that comes later
+        // in the launch would read the rows of step t + 1 where they were overwritten)
+        if (want && T > 0 && shape->digits == 3 && !d_row_select && !d_records && n_tiles > 0 && !(in_place && d_values) &&
             oc_internal_fold_args(e, d_actions, d_obs, d_reward, d_done, &probe, &fp.lds_need) == OC_OK &&
             fp.lds_need <= static_cast<size_t>(staging_bytes(static_cast<int>(shp[2] * shp[3] * shp[4]))) &&
             oc_internal_fold_workspace(e, &cnt, &expd, &groups, &tmpl) == OC_OK) {
