@@ -6,6 +6,14 @@
 #error "define OC_NS (the namespace of this specialisation) before including oc_step_body.h"
 #endif
 
+// kitchens a group OWNS (OC_KPW sizes LDS and the state registers: one kitchen more under OC_HALO_R)
+#undef KP_group
+#if defined(OC_GROUP_K)
+#define KP_group(a) (OC_GROUP_K)
+#else
+#define KP_group(a) KP_kpw(a)
+#endif
+
 namespace oc_dev {
 namespace OC_NS {
 
@@ -36,7 +44,11 @@ __device__ __forceinline__ LdsView carve(uint32_t *base, const StepArgs &a) {
     v.state = p;
     p += align4(KP_kpw(a) * KP_lstride(a));
     v.stage[0] = p;
+#if defined(OC_HALO_R) && OC_HALO_R > 0
+    v.stage[1] = p + (KP_gpasses(a) * kWave + 16) * kTileDwords;   // (16 tiles in front of each viewer's passes: what one flush leaves to the next, see step_body)
+#else
     v.stage[1] = p + KP_gpasses(a) * kWave * kTileDwords;
+#endif
     return v;
 }
 
@@ -139,11 +151,41 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
 #else
     constexpr bool kXW = false;
 #endif
+    // ---- OC_HALO_R (specialised build of the module for fresh destinations, for an engine whose planes can start off a 64-byte
+    // boundary: a kitchen count whose planes are no multiple of 64 bytes).  A 64-byte word of memory written by two store
+    // instructions -- let alone two wavefronts -- costs a read-modify-write each time, and with a plane starting 16 / 32 / 48 bytes
+    // off, every 1 KB store instruction of its flushes splits two words (65 535 kitchens of cramped_room into time-major slots: 18.3 us
+    // per launch against 11.9 at 65 536; there viewer 0's plane is 0 or 32 bytes off depending on the slot, viewer 1's 48 or 16).
+    // A plane's bytes are therefore owned in ranges that start r tiles EARLY, 20 r = the plane's offset mod 64 (r = 0, 4, 8, 12; read
+    // off the pointers, per viewer and launch): a group of OC_GROUP_K kitchens [k0, k1) writes viewer v's tiles [k0 S - r_v, k1 S - r_v)
+    // -- the last r_v tiles of kitchen k0 - 1, which it loads and steps as a halo kitchen like the per-XCD experiment above, and not
+    // its own last r_v (the next group's).  Passes start at tile k0 S - R, R = max r_v, so the flushes of the viewer with r_v = R begin
+    // and end on 64-byte boundaries; the other viewer's lag 16 - (R - r_v) tiles behind the passes, the tiles a flush leaves over
+    // waiting in a 16-tile area in front of its staged passes.  The plane's first group starts at tile 0 and its last group ends at
+    // N S: two groups of a launch keep split words.  Correct for any plane address: only the alignment depends on it.
+    // Streaming stores only: plain stores (fresh slots that a policy launch reads next) merge their partial words in L2, and the halo
+    // kitchen, the extra tiles and the sixth pass of a 16-kitchen group are then pure cost -- collecting with the policies in the
+    // loop at 65 535 kitchens 51.6 against 49.8 us per step.
+#if defined(OC_HALO_R) && OC_HALO_R > 0 && !defined(OC_XW_SUM)
+    constexpr bool kHR = !FUSED && !BATCH && SM != SM_PLAIN;
+    constexpr int kCarry = kHR ? 16 * kTileDwords : 0;
+#else
+    constexpr bool kHR = false;
+    constexpr int kCarry = 0;
+#endif
+    int hr_r[2] = {0, 0}, hr_R = 0;                  // (wave-uniform)
+    if (kHR) {
+        const uint32_t m0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.obs)) & 63u;
+        const uint32_t m1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.obs + a.obs_player_stride)) & 63u;
+        if (((m0 | m1) & 15u) == 0) { hr_r[0] = static_cast<int>(m0 >> 4) * 4; hr_r[1] = static_cast<int>(m1 >> 4) * 4; }
+        hr_R = max(hr_r[0], hr_r[1]);
+    }
     struct Geom {
         int64_t k0;          // first kitchen in LDS (the halo kitchen if there is one)
         int n_lds, halo;     // kitchens in LDS; how many of them (0 / 1), in front, are not the group's own
         int64_t tile0;       // first tile of the group's byte range, flat index kitchen * S + tile
         int ntiles, nflush;  // tiles to encode from tile0 on; tiles whose bytes the group writes
+        bool first, last;    // (OC_HALO_R) the plane's first / last group
     };
     auto geom_of = [&](int g, int item) {
         Geom G;
@@ -156,11 +198,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
         } else
 #endif
         {
-            k0 = static_cast<int64_t>(BATCH ? g - item * a.batch_groups : g) * KP_kpw(a);
-            nk = KP_kpw(a);
+            k0 = static_cast<int64_t>(BATCH ? g - item * a.batch_groups : g) * KP_group(a);
+            nk = KP_group(a);
         }
         nk = static_cast<int>(max(static_cast<int64_t>(0), min(static_cast<int64_t>(nk), KP_n_kitchens(a) - k0)));
-        if (kXW && nk > 0) {
+        G.first = false; G.last = false;
+        if (kHR && nk > 0) {
+            G.first = k0 == 0; G.last = k0 + nk >= KP_n_kitchens(a);
+            G.halo = (G.first || hr_R == 0) ? 0 : 1;
+            G.k0 = k0 - G.halo; G.n_lds = nk + G.halo;
+            G.tile0 = G.first ? 0 : k0 * S - hr_R;
+            G.ntiles = G.nflush = static_cast<int>((k0 + nk) * S - G.tile0);
+        } else if (kXW && nk > 0) {
             const int64_t k1 = k0 + nk;
             const int64_t t_lo = (k0 * S) & ~static_cast<int64_t>(15);
             const int64_t t_hi = k1 >= KP_n_kitchens(a) ? KP_n_kitchens(a) * S : (k1 * S) & ~static_cast<int64_t>(15);
@@ -253,7 +302,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
         const Geom G = geom_of(group, item);
         const int64_t k0 = G.k0;                     // first kitchen in LDS
         const int n_valid = G.n_lds;                 // kitchens in LDS: all of them are stepped, the group's own are written back
-        const int halo = kXW ? G.halo : 0;
+        const int halo = (kXW || kHR) ? G.halo : 0;
         const int nq = n_valid * KP_recq(a);
 
         // ---- prefetched state block -> LDS, then start fetching the next group
@@ -341,7 +390,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                     posor = pos0 | (or0 << 8) | (pos1 << 16) | (static_cast<uint32_t>(or1) << 24);
                     if (is_done) { posor = KP_start_posor(a); h0 = 0; h1 = 0; ts = 0; }
                     rec[S] = posor; rec[S + 1] = h0; rec[S + 2] = h1; rec[S + 3] = static_cast<uint32_t>(ts);
-                    if (lane >= halo) {                      // (a halo kitchen's outputs are its owner's)
+                    if (lane >= halo && !(KP_ablate(a) & 32)) {   // (a halo kitchen's outputs are its owner's; bit 32: diagnostics, timing only)
                         reward_t[kid] = rew;                 // envs/overcooked2_env.py:336-339: sum, to every player
                         reward_t[KP_n_kitchens(a) + kid] = rew;
                         done_t[kid] = static_cast<int32_t>(is_done);
@@ -360,7 +409,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
 
             // ---- phase E: lane = tile, in output order o = x*H + y per kitchen (envs/overcooked2_env.py:324)
             int k = k_first, o = o_first;
-            if (kXW) {                                       // the byte range starts tile0 - k0*S tiles into the LDS kitchens
+            if (kXW || kHR) {                                // the byte range starts tile0 - k0*S tiles into the LDS kitchens
                 const int f = static_cast<int>(G.tile0 - k0 * S) + lane;
                 k = f / S; o = f - k * S;
             }
@@ -402,7 +451,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 const uint32_t d3 = r.tab.y | (inpot ? ((obj << 16) & 0xFF000000u) : 0u);      // ch15 = onions in the pot
                 const uint32_t d4 = (inpot ? static_cast<uint32_t>(max(tk, 0)) : 0u) | lying | hands;
                 const uint32_t thi = r.tab.x >> 16;          // terrain bits of channels 10,11 (ref:165-171)
-                uint32_t *s0 = r.active ? L.stage[0] + slot : L.dump, *s1 = r.active ? L.stage[1] + slot : L.dump + 8;
+                uint32_t *s0 = r.active ? L.stage[0] + kCarry + slot : L.dump, *s1 = r.active ? L.stage[1] + kCarry + slot : L.dump + 8;
                 // bytes: [self here, other here, self orient x4, other orient x4, terrain ...]
                 s0[0] = e0 | (e1 << 8) | (A << 16); s0[1] = __builtin_amdgcn_alignbit(B, A, 16); s0[2] = __builtin_amdgcn_alignbit(thi, B, 16); s0[3] = d3; s0[4] = d4;
                 s1[0] = e1 | (e0 << 8) | (B << 16); s1[1] = __builtin_amdgcn_alignbit(A, B, 16); s1[2] = __builtin_amdgcn_alignbit(thi, A, 16); s1[3] = d3; s1[4] = d4;
@@ -463,7 +512,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 constexpr int kFullChunks = kFullBytes / 16, kIts = (kFullChunks + kWave - 1) / kWave;
                 // (also for ranges that do not start on a 64-byte boundary: this is the in-place path, whose stores the Infinity Cache
                 // absorbs -- 65 535 kitchens 11.41 us with it, 11.77 through the lane-shifting loop below)
-                if (VEC16 && kFullBytes % 16 == 0 && kIts <= 6 && gbytes == kFullBytes) {
+                if (!kHR && VEC16 && kFullBytes % 16 == 0 && kIts <= 6 && gbytes == kFullBytes) {
                     uint4 r[2][kIts];
 #pragma unroll
                     for (int v = 0; v < 2; ++v)
@@ -486,13 +535,28 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                     return;
                 }
 #endif
+                // (OC_HALO_R: the tiles of this flush, counted from the group's first encoded tile)
+                const int t_beg = p0 * tpp, t_end = min((p0 + count) * tpp, ntiles);
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
                     if (KP_ablate(a) & 2) break;
                     int8_t *dst = obs_t + v * a.obs_player_stride + goff;
-                    const uint32_t *src = L.stage[v];
+                    const uint32_t *src = L.stage[v] + kCarry;
+                    int vbytes = gbytes;
+                    if (kHR) {
+                        // this viewer's tiles of the flush: from its own first tile on, `lag` tiles behind the passes until the group's
+                        // last flush, which ends r tiles before the last encoded one (the next group's, unless there is none)
+                        const int r = hr_r[v];
+                        const int lag = (G.first || r == hr_R) ? 0 : 16 - (hr_R - r);
+                        const int vend = G.last ? ntiles : ntiles - r;
+                        const int fb = p0 == 0 ? (G.first ? 0 : hr_R - r) : t_beg - lag;
+                        const int fe = t_end >= ntiles ? vend : min(t_end - lag, vend);
+                        vbytes = max(0, fe - fb) * kChannels;
+                        src += (fb - t_beg) * kTileDwords;            // (may point into the 16 tiles in front of the passes)
+                        dst = obs_t + v * a.obs_player_stride + (G.tile0 + fb) * kChannels;
+                    }
                     if (VEC16) {
-                        const int nfull = gbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
+                        const int nfull = vbytes >> 4;            // whole 16-byte chunks: 1 KiB per wave store
                         // Every store instruction starts on a 64-byte boundary of memory: when the range does not (a viewer plane behind
                         // an odd number of kitchens, a group size that is no multiple of 64 bytes), the first instruction's leading lanes
                         // stay idle instead.  A 64-byte word written by two instructions costs a read-modify-write each time --
@@ -501,10 +565,24 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                         const int sh = static_cast<int>((reinterpret_cast<uintptr_t>(dst) >> 4) & 3);     // (wave-uniform)
                         for (int c = lane - sh; c < nfull; c += kWave)
                             if (c >= 0) store16<SM>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
-                        const int rem = (gbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
+                        const int rem = (vbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
                         if (lane < rem) store4(dst + nfull * 16 + lane * 4, src[nfull * 4 + lane]);
                     } else {
-                        for (int c = lane; c * 4 < gbytes; c += kWave) store4(dst + c * 4, src[c]);
+                        for (int c = lane; c * 4 < vbytes; c += kWave) store4(dst + c * 4, src[c]);
+                    }
+                }
+                if (kHR && !G.first && t_end < ntiles) {
+                    // the last `lag` tiles of these passes wait for the next flush in front of the staged passes (16-byte chunks: lag
+                    // is a multiple of four tiles; LDS operations of a wavefront complete in order, the flush's reads above come first)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        const int lag = hr_r[v] == hr_R ? 0 : 16 - (hr_R - hr_r[v]);
+                        const uint32_t *from = L.stage[v] + kCarry + (t_end - t_beg - lag) * kTileDwords;
+                        uint32_t *to = L.stage[v] + kCarry - lag * kTileDwords;
+                        if (lane < lag * kTileDwords / 4) {
+                            const uint4 t = *reinterpret_cast<const uint4 *>(from + 4 * lane);
+                            *reinterpret_cast<uint4 *>(to + 4 * lane) = t;
+                        }
                     }
                 }
             };

@@ -606,3 +606,35 @@ def test_per_xcd_group_sizes_with_a_halo_kitchen_on_the_diagnostics_build(clean_
     for argv in (["cramped_room", "8191", "24", "19,13,17,15,16,0,23,1"], ["coordination_ring", "6001", "20", "17,15,17,15,17,15,17,15"]):
         r = clean_launcher.run([sys.executable, "tools/check_xcc_weights.py"] + argv, env={"OC_DIAGNOSTICS": "1"}, timeout=600)
         assert r["rc"] == 0 and "bit-exact" in r["stdout"], r["stdout"][-1500:] + r["stderr"][-800:]
+
+
+@pytest.mark.parametrize("layout,n", [("cramped_room", 49153), ("cramped_room", 49154), ("cramped_room", 49155), ("asymmetric_advantages", 49157)])
+def test_time_major_steps_when_the_viewer_planes_start_off_64_byte_boundaries(layout, n):
+    """Kitchen counts whose planes are no multiple of 64 bytes: the second viewer's plane, and every other time-major slot, then start
+    16 / 32 / 48 bytes off a boundary, and the module for fresh destinations owns each plane's bytes in ranges that start a few tiles
+    early, the neighbour's last kitchen stepped as a halo (oc_step_body.h, OC_HALO_R).  Every kitchen against the oracle, into
+    consecutive slots (both slot parities), records included, in place in between."""
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+    from oracle import oracle
+    params = get_base_layout_params(layout, 9)
+    eng = OvercookedEngine(params, n, 0)
+    ora = oracle.OracleVecEnv(params, n)
+    W, H = params["width"], params["height"]
+    T = 14
+    slots = torch.zeros((T, 2, n, W, H, 20), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((T, 2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    recs = torch.zeros((T, n, eng.export_states().shape[-1]), dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for t in range(T):
+        a = torch.randint(0, 6, (2, n), device="cuda", dtype=torch.int32, generator=g)
+        if t % 5 == 4:
+            obs, r, d = eng.step(a)
+        else:
+            obs, r, d = eng.step(a, obs=slots[t], reward=rew[t], done=done[t], records=recs[t])
+        oobs, orew, odone = ora.step(a.cpu().numpy())
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(r.cpu().numpy(), orew) and np.array_equal(d.cpu().numpy().astype(bool), np.asarray(odone).astype(bool)), t
+        if t % 5 != 4:
+            assert torch.equal(recs[t], eng.export_states()), t
+    eng.close()

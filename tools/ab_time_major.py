@@ -33,7 +33,8 @@ for cand in cands:
     elif "OC_XCC_WEIGHTS" in os.environ and not os.environ.get("OC_XCC_WEIGHTS_KEEP"):
         os.environ.pop("OC_XCC_WEIGHTS")
     e = OvercookedEngine(params, n, 0)
-    e.set_tuning(*cand[:3])
+    if cand[0]:                                           # (0,0,0: the engine's own choice, fresh geometry included)
+        e.set_tuning(*cand[:3])
     engines.append(e)
 W, H = params["width"], params["height"]
 obs = torch.zeros((slots, 2, n, W, H, 20), dtype=torch.int8, device="cuda")
@@ -42,11 +43,12 @@ done = torch.zeros((slots, n), dtype=torch.int32, device="cuda")
 res = [[] for _ in cands]
 for r in range(7):
     for i, e in enumerate(engines):
-        e.rollout(acts, slots, obs=obs, reward=rew, done=done)
+        kw = dict(obs=obs) if os.environ.get("OC_AB_OBS_ONLY") else dict(obs=obs, reward=rew, done=done)   # (obs only: rewards / dones in place)
+        e.rollout(acts, slots, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(8):
-            e.rollout(acts, slots, obs=obs, reward=rew, done=done)
+            e.rollout(acts, slots, **kw)
         torch.cuda.synchronize()
         res[i].append((time.perf_counter() - t0) / (8 * slots) * 1e6)
 for c, r in zip(cands, res):
