@@ -562,9 +562,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                         // stay idle instead.  A 64-byte word written by two instructions costs a read-modify-write each time --
                         // 65 535 kitchens of cramped_room (plane 1 starts 48 bytes off) into time-major slots: 18.3 us per launch
                         // against 11.9 at 65 536 (round 4).
+                        // (a loop of its own for that case: the aligned one, which is every power-of-two batch, pays nothing for it --
+                        // as one loop with the shift as a variable config 4's split ran 2.5 % slower, config 3's launch 3 %)
                         const int sh = static_cast<int>((reinterpret_cast<uintptr_t>(dst) >> 4) & 3);     // (wave-uniform)
-                        for (int c = lane - sh; c < nfull; c += kWave)
-                            if (c >= 0) store16<SM>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
+                        if (sh == 0) {
+                            for (int c = lane; c < nfull; c += kWave) store16<SM>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
+                        } else {
+                            for (int c = lane - sh; c < nfull; c += kWave)
+                                if (c >= 0) store16<SM>(dst + c * 16, *reinterpret_cast<const uint4 *>(src + 4 * c));
+                        }
                         const int rem = (vbytes & 15) >> 2;       // 0..3 dwords, ragged tail of the very last group only
                         if (lane < rem) store4(dst + nfull * 16 + lane * 4, src[nfull * 4 + lane]);
                     } else {
