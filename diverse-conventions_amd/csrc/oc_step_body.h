@@ -173,8 +173,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
     constexpr bool kHR = false;
     constexpr int kCarry = 0;
 #endif
+    // A halo kitchen is READ by a group that does not own it, in the launch in which its owner -- another wavefront -- writes its
+    // post-step record: the launch therefore reads every record from a.state and writes it to a.state_out, a second block that the
+    // host swaps with the first after the launch (launch() in overcooked_engine.hip).  Without one (a launch being captured into a
+    // graph, whose replays could not swap) there are no halo kitchens: r = 0, the lane-shifted flush loop below.
     int hr_r[2] = {0, 0}, hr_R = 0;                  // (wave-uniform)
-    if (kHR) {
+    if (kHR && a.state_out) {
         const uint32_t m0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.obs)) & 63u;
         const uint32_t m1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.obs + a.obs_player_stride)) & 63u;
         if (((m0 | m1) & 15u) == 0) { hr_r[0] = static_cast<int>(m0 >> 4) * 4; hr_r[1] = static_cast<int>(m1 >> 4) * 4; }
@@ -634,7 +638,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
         if (KP_trace(a) && stamp[4] == 0) stamp[4] = __builtin_amdgcn_s_memrealtime();
         // ---- state block LDS -> HBM
         if (STEP && !(KP_ablate(a) & 8)) {
-            uint4 *dst = a.state + k0 * KP_recq(a);
+            uint4 *dst = (((kHR || kXW) && a.state_out) ? a.state_out : a.state) + k0 * KP_recq(a);
 #pragma unroll
             for (int q = 0; q < QN; ++q)
                 if (lane + q * kWave < nq && lane + q * kWave >= halo * KP_recq(a)) {

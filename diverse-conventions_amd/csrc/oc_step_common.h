@@ -196,6 +196,9 @@ struct StepArgs {
     // aligned), step t of a FUSED rollout to rec_out + t * rec_step_stride; NULL = not recorded
     uint4 *rec_out;
     int64_t rec_step_stride;    // uint4 between consecutive steps' record blocks (FUSED kernels only)
+    // builds whose groups read a neighbour's kitchen (OC_HALO_R, OC_XW_SUM: oc_step_body.h): where the post-step records go instead
+    // of `state` -- a second block of the same size, swapped with the first by the host after the launch; NULL = in place, no halo
+    uint4 *state_out;
     int32_t ablate;             // diagnostics build only (tools/ablate.py): phases to skip; always 0 in the product library
     unsigned long long *trace;  // diagnostics build only: [wave][8] s_memrealtime stamps (100 MHz); always NULL in the product library
 };

@@ -227,6 +227,10 @@ class GroupPairedRollout:
         T = trajs[0].T
         if any(t.T != T for t in trajs):
             raise ValueError("the trajectories of a group rollout must share one length")
+        if len(trajs) != len(self.group.engines) or any(t.engine is not e for t, e in zip(trajs, self.group.engines)):
+            raise ValueError("one trajectory per engine of the group, in the group's order")
+        for t in trajs:
+            t.require_time_major_obs("collect()")
         for t in trajs:
             t.start()
         none = [None] * len(trajs)

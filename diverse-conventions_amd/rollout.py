@@ -147,6 +147,9 @@ class FusedPairedRollout:
         """Fill a TrajectoryBuffer: step t reads `traj.obs[t]`, writes actions straight into `traj.actions[t]` and the
         env step writes `traj.obs[t+1]`, `traj.reward[t]`, `traj.done[t]` -- two launches per step, no copies.
         logp / values: optional float32 [T, 2, N] destinations."""
+        traj.require_time_major_obs("collect()")
+        if traj.engine is not self.engine:
+            raise ValueError("the trajectory belongs to another engine")
         traj.start()
         for name, t in (("logp", logp), ("values", values)):
             if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(traj.actions.shape)):

@@ -68,6 +68,14 @@ class TrajectoryBuffer:
     def _obs_slot(self, t):
         return self.obs[t if self.obs_slots > 1 else 0]
 
+    def require_time_major_obs(self, who):
+        """Callers that hand `obs` to a native rollout which writes slot t+1 at step t (T+1 slots behind the pointer): a buffer
+        with `obs_slots=1` holds one slot, and the rollout would write T slots past its end."""
+        slot = self.obs[0].numel()
+        if self.obs_slots != self.T + 1 or self.obs.numel() != (self.T + 1) * slot or not self.obs.is_contiguous():
+            raise ValueError(f"{who} fills time-major observation slots: the trajectory needs obs_slots = T + 1 "
+                             f"(this one has {self.obs_slots} for T = {self.T})")
+
     def start(self):
         """Slot 0 := observation of the engine's current states (episodes keep running, like n_reset)."""
         self.t = 0
@@ -101,8 +109,7 @@ class TrajectoryBuffer:
     def rollout(self, actions):
         """Fill the whole buffer from a pre-drawn action tape [T, P, N] in ONE launch (oc_rollout_fused: the
         kitchens' state stays on chip between steps; 9.5 vs 13.6 us per step at 65 536 kitchens)."""
-        if self.obs_slots == 1:
-            raise ValueError("rollout() fills time-major observation slots")
+        self.require_time_major_obs("rollout()")
         self.start()
         self.actions.copy_(actions.reshape(self.T, self.P, -1))
         self.engine.rollout_fused(self.T, actions=self.actions, obs=self.obs[1:], reward=self.reward, done=self.done,

@@ -325,3 +325,36 @@ def test_policy_rollout_into_fresh_slots_at_the_large_batch_geometry(layout_para
             got = lp.gather(-1, traj.actions[:, p, f:f + 64].long().unsqueeze(-1)).squeeze(-1)
             assert (got - logp[:, p, f:f + 64]).abs().max() < 8e-6
     eng.close()
+
+
+def test_collecting_into_a_single_slot_trajectory_is_refused(layout_params):
+    """`TrajectoryBuffer(obs_slots=1)` holds ONE observation slot; the native policy rollouts write slot t+1 at step t, T slots past
+    its end.  Every collecting entry point refuses such a buffer (and one that belongs to another engine) before anything is enqueued."""
+    from diverse_conventions_amd import (EngineGroup, FusedPairedRollout, GroupPairedRollout, OvercookedEngine, PackedNetworks,
+                                         TrajectoryBuffer)
+    params = layout_params["simple"]
+    k, threads, T = 1, 40, 5
+    n = threads * (2 * k + 1)
+    actors, _ = _random_nets(5, 4, k + 1, 0, 5)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=actors)
+    eng, other = OvercookedEngine(params, n, 0), OvercookedEngine(params, n, 0)
+    ro = FusedPairedRollout(eng, nets, threads, k, seed=1)
+    one = TrajectoryBuffer(eng, T, obs_slots=1)
+    canary = one.obs.clone()
+    with pytest.raises(ValueError, match="obs_slots"):
+        ro.collect(one)
+    with pytest.raises(ValueError, match="obs_slots"):
+        one.rollout(torch.zeros((T, 2, n), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError, match="another engine"):
+        ro.collect(TrajectoryBuffer(other, T))
+    grp = EngineGroup([eng])
+    gro = GroupPairedRollout(grp, [nets], [threads], k, seed=1)
+    with pytest.raises(ValueError, match="obs_slots"):
+        gro.collect([one])
+    with pytest.raises(ValueError, match="one trajectory per engine"):
+        gro.collect([TrajectoryBuffer(other, T)])
+    torch.cuda.synchronize()
+    assert torch.equal(one.obs, canary)
+    ro.collect(TrajectoryBuffer(eng, T))                      # (the ordinary buffer still collects)
+    grp.close()
+    eng.close(); other.close()

@@ -638,3 +638,79 @@ def test_time_major_steps_when_the_viewer_planes_start_off_64_byte_boundaries(la
         if t % 5 != 4:
             assert torch.equal(recs[t], eng.export_states()), t
     eng.close()
+
+
+@pytest.mark.parametrize("cus", [2, 0])
+def test_halo_kitchens_are_read_from_the_block_the_launch_does_not_write(cus):
+    """The wavefront that owns a halo kitchen writes its post-step record in the same launch in which its neighbour reads the
+    pre-step one: such launches read one record block and write the other (halo_state_out in overcooked_engine.hip), so the order in
+    which wavefronts run cannot matter.  Here they run in very different orders: 131 075 kitchens = 8193 groups on the 16 persistent
+    wavefronts of two CUs (512 groups each, a wavefront's later groups long after its neighbours' earlier ones) and on the whole chip;
+    every kitchen against the oracle, records included, with in-place steps (which do not swap the blocks) in between."""
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params, native
+    params = get_base_layout_params("cramped_room", 7)
+    n, T = 131075, 9
+    eng = OvercookedEngine(params, n, 0)
+    if cus:
+        native.check(native.lib().oc_exp_set_cu_budget(eng._handle, cus))
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    slots = torch.zeros((3, 2, n, params["width"], params["height"], 20), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros(n, dtype=torch.int32, device="cuda")
+    recs = torch.zeros((n, eng.export_states().shape[-1]), dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(T):
+        a = torch.randint(0, 6, (2, n), device="cuda", dtype=torch.int32, generator=g)
+        if t in (3, 6):
+            obs, r, d = eng.step(a)
+        else:
+            obs, r, d = eng.step(a, obs=slots[t % 3], reward=rew, done=done, records=recs)
+        oobs, orew, odone = ora.step(a.cpu().numpy())
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(r.cpu().numpy(), orew) and np.array_equal(d.cpu().numpy().astype(bool), np.asarray(odone).astype(bool)), t
+        if t not in (3, 6):
+            assert torch.equal(recs, eng.export_states()), t
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    eng.close()
+
+
+def test_a_captured_step_into_a_fresh_slot_replays_without_halo_kitchens():
+    """A launch captured into a graph cannot swap record blocks on replay, so it runs without halo kitchens (state_out NULL): the same
+    graph replayed three times against the oracle, at a kitchen count whose planes start off 64-byte boundaries."""
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+    params = get_base_layout_params("cramped_room", 50)
+    n = 49155
+    eng = OvercookedEngine(params, n, 0)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng.prepare_kernels()
+    a = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    slots = torch.zeros((2, 2, n, params["width"], params["height"], 20), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros(n, dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    draw = lambda: torch.randint(0, 6, (2, n), device="cuda", dtype=torch.int32, generator=g)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for i in range(2):                                   # (eager: these launches have halo kitchens and swap the blocks)
+            a.copy_(draw())
+            eng.step(a, obs=slots[i % 2], reward=rew, done=done)
+            ora.step(a.cpu().numpy())
+    torch.cuda.current_stream().wait_stream(s)
+    a.copy_(draw())
+    host_a = a.cpu().numpy()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.step(a, obs=slots[0], reward=rew, done=done)
+    for i in range(3):
+        if i:
+            a.copy_(draw())
+            host_a = a.cpu().numpy()
+        graph.replay()
+        oobs, orew, odone = ora.step(host_a)
+        assert np.array_equal(slots[0].cpu().numpy(), oobs), i
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy().astype(bool), np.asarray(odone).astype(bool)), i
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    eng.close()
