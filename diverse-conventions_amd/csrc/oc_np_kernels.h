@@ -38,6 +38,7 @@ struct NpArgs {
     int32_t horizon, placement_rew, soup_rew;
     int32_t rvalues[16], rtimes[16];
     uint32_t start_pp[kMaxP];
+    uint32_t *rec_out;              // encode launch of a step: the records it reads also go here ([N][recd], the trajectory's slot); NULL: not recorded
 };
 
 __device__ __forceinline__ int np_delta(int d, int W) { return d == A_NORTH ? -W : d == A_SOUTH ? W : d == A_EAST ? 1 : d == A_WEST ? -1 : 0; }   // ref:22-32
@@ -180,7 +181,13 @@ __global__ __launch_bounds__(kNpThreads) void np_encode_kernel(const NpArgs a) {
     int8_t *stage = reinterpret_cast<int8_t *>(np_lds + rec_dwords);           // [P][per_viewer]
     const int per_viewer = (kpb * S * C + 15) / 16 * 16;
     // records -> LDS, staging ranges -> 0
-    for (int i = threadIdx.x; i < nk * recd; i += kNpThreads) recs[i] = a.state[k0 * recd + i];
+    // (a recorded step: the post-step records this block reads anyway leave for the trajectory's record slot from here -- the same
+    // coalesced dwords, no copy pass over the state block behind the step)
+    for (int i = threadIdx.x; i < nk * recd; i += kNpThreads) {
+        const uint32_t w = a.state[k0 * recd + i];
+        recs[i] = w;
+        if (a.rec_out) a.rec_out[k0 * recd + i] = w;
+    }
     for (int i = threadIdx.x; i < per_viewer * P / 16; i += kNpThreads) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     if (threadIdx.x < ntiles) {

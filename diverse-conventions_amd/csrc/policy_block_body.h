@@ -325,14 +325,19 @@
         int best = 0;
         float best_lp = 0.f;
         if (a.sample) {
-            // cumulative masses of this half's actions (half 1 starts behind half 0's); an action past n_out adds nothing and its
-            // cumulative value is the total, which u x total stays below (u < 1) -- rounding up to it is caught by the clamp
+            // cumulative masses of this half's actions (half 1 starts behind half 0's; an action past n_out adds nothing).  The
+            // threshold is u x the LAST cumulative value of that very chain -- half 1's, which `sum` = own + other equals only up to
+            // rounding -- and u <= 1 - 2^-24 keeps the f32 product strictly below it: the count therefore always stops at an action
+            // whose own mass moved the chain past the threshold (mass > 0), never at one behind the last such (the clamp below is
+            // unreachable; with u x sum a threshold rounded up to the chain's end selected action n_out - 1 whatever its mass).
             const float u = oc_policy_uniform_from_hash(oc_policy_hash(S.seed, counter, static_cast<uint32_t>(row), 0));
-            const float thr = u * sum;
-            float c = h ? other : 0.f;
+            float c = h ? other : 0.f, cum[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { c += ex[r]; cum[r] = c; }
+            const float thr = u * __shfl(c, lane | 32);
             int cnt = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { c += ex[r]; cnt += c <= thr ? 1 : 0; }
+            for (int r = 0; r < 4; ++r) cnt += cum[r] <= thr ? 1 : 0;
             best = min(cnt + __shfl_xor(cnt, 32), n_out - 1);
             const int local = best - 4 * h;
             float lp_sel = 0.f;

@@ -65,11 +65,22 @@ def pack_host(state_dict, obs_shape, head=ACTOR_HEAD, digits=DEFAULT_DIGITS) -> 
     return out
 
 
+ACTIVATION_LIMIT = 65504.0 / 16.0   # = 4094: where the kernel's hidden activations saturate (PackedNetworks)
+
+
 class PackedNetworks:
     """`n_nets` networks of one observation shape in the kernel's weight image, resident in HBM.
 
     `pack(i, state_dict, head)` converts reference-format tensors (host or device) on the device; call it again
-    after every optimiser step for the networks that changed."""
+    after every optimiser step for the networks that changed.
+
+    Range.  The dense layers run on f16 two-piece operands: every hidden activation (conv, fc1, fc2 outputs after the
+    ReLU) travels at 2^4 x its value and is clamped at 65 504, i.e. **activations above `ACTIVATION_LIMIT` = 4094 saturate** where the
+    reference's f32 forward does not, and a layer whose weights span more than ~2^14 in magnitude loses the low bits of its
+    smallest weights (below 2^-24 of the layer's largest product).  Networks of the reference's training stay orders of magnitude
+    inside both (activations of O(1-100)); `activation_range(i, obs)` evaluates network i in f32 with PyTorch on the rows given and
+    reports the largest activation per layer, `pack(..., check_finite=True)` (the default) refuses NaN / Inf weights -- the
+    device-side scale search skips non-finite weights, so they would otherwise pack into garbage silently."""
 
     def __init__(self, obs_shape, n_nets, device, digits=DEFAULT_DIGITS):
         self.W, self.H = int(obs_shape[0]), int(obs_shape[1])
@@ -86,10 +97,12 @@ class PackedNetworks:
         self.n_out = [0] * self.n_nets
         self._keep = {}
 
-    def pack(self, index, state_dict, head=ACTOR_HEAD):
+    def pack(self, index, state_dict, head=ACTOR_HEAD, check_finite=True):
         """state_dict: an R_Actor / R_Critic of the reference's default configuration -- CNNBase with ReLU (`--use_ReLU`
         left at its default; the activation has no parameters, so a Tanh network cannot be told apart here) and no
-        recurrent layer (`--use_recurrent_policy` off, as in every training script of the reference)."""
+        recurrent layer (`--use_recurrent_policy` off, as in every training script of the reference).
+        check_finite: raise ValueError on NaN / Inf parameters (one device reduction and a host read per call -- pack() runs once
+        per optimiser step, not per env step; pass False inside a stream capture)."""
         if any(k.startswith("rnn.") for k in state_dict):
             raise NotImplementedError("recurrent policies (rnn.* parameters) are not evaluated by the fused kernel; "
                                       "the reference's training scripts do not enable them")
@@ -99,11 +112,32 @@ class PackedNetworks:
         P = (self.W - 2) * (self.H - 2)
         if tuple(src[0].shape) != (hidden // 2, 20, 3, 3) or tuple(src[2].shape) != (hidden, hidden // 2 * P):
             raise ValueError(f"network {index} does not have the reference CNNBase shape for a {self.W}x{self.H} grid")
+        if check_finite and not bool(torch.stack([x.isfinite().all() for x in src]).all()):
+            bad = [k for k, x in zip(_KEYS + (head + ".weight", head + ".bias"), src) if not bool(x.isfinite().all())]
+            raise ValueError(f"network {index}: non-finite values in {', '.join(bad)}")
         self._keep[index] = src                      # the pack kernel reads them asynchronously
+        self._heads = getattr(self, "_heads", {})
+        self._heads[index] = head
         native.check(native.lib().oc_policy_pack(ctypes.byref(_shape(self.W, self.H, n_out, self.digits, hidden)),
                                                  *[_ptr(x) for x in src], _ptr(self.image[index]), _stream(self.device)))
         self.n_out[index] = n_out
         return index
+
+    def activation_range(self, index, obs):
+        """Largest hidden activation of network `index` on the rows `obs` (int8 / float [n, W, H, 20], any device), evaluated in f32
+        by PyTorch from the tensors `pack` was given (train/MAPPO/utils/cnn.py:26-38) -> {"conv", "fc1", "fc2": max after the ReLU,
+        "out": max |head output|, "limit": ACTIVATION_LIMIT, "saturates": any hidden layer above the limit}.  An audit to run on a
+        sample of real observations when networks come from somewhere else than the reference's training (hand-set weights,
+        other initialisations): above the limit the fused kernel's outputs differ from the reference's."""
+        cw, cb, w1, b1, w2, b2, wh, bh = self._keep[index]
+        x = torch.as_tensor(obs).to(device=self.device, dtype=torch.float32).reshape(-1, self.W, self.H, 20).permute(0, 3, 1, 2)
+        c = torch.relu(torch.nn.functional.conv2d(x, cw, cb))                 # Conv2d on [B, C, W, H], flatten (o, x', y')
+        f1 = torch.relu(torch.nn.functional.linear(c.flatten(1), w1, b1))
+        f2 = torch.relu(torch.nn.functional.linear(f1, w2, b2))
+        out = torch.nn.functional.linear(f2, wh, bh)
+        r = {"conv": float(c.max()), "fc1": float(f1.max()), "fc2": float(f2.max()), "out": float(out.abs().max()), "limit": ACTIVATION_LIMIT}
+        r["saturates"] = max(r["conv"], r["fc1"], r["fc2"]) > ACTIVATION_LIMIT
+        return r
 
     @classmethod
     def from_state_dicts(cls, obs_shape, device, actors: Sequence[dict] = (), critics: Sequence[dict] = (), digits=DEFAULT_DIGITS):
@@ -342,9 +376,6 @@ def draw_uniform(seed, counter, row, action=0):
     """The counter-hash uniform of (seed, counter, row, action).  The kernel draws a row's action by inverse CDF from the uniform of
     action 0 (the first action whose cumulative probability exceeds it): lets a test re-derive every sampled action."""
     return float(native.lib().oc_policy_uniform(int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, int(row), int(action)))
-
-
-gumbel_uniform = draw_uniform          # (the name of rounds 1-3, when the draw was Gumbel-max over six uniforms per row)
 
 
 class FusedVectorAgent:

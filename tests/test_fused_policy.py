@@ -15,7 +15,7 @@ import torch
 
 from conftest import GOLDEN
 from diverse_conventions_amd import native
-from diverse_conventions_amd.fused_policy import (ACTOR_HEAD, CRITIC_HEAD, TILE_ACT, PackedNetworks, PolicyPlan, gumbel_uniform,
+from diverse_conventions_amd.fused_policy import (ACTOR_HEAD, CRITIC_HEAD, TILE_ACT, PackedNetworks, PolicyPlan, draw_uniform,
                                                   pack_host, packed_bytes, plan_tiles)
 from oracle.policy_oracle import emulate_packed, log_softmax, parse_image, reference_forward
 
@@ -207,7 +207,7 @@ def test_recurrent_state_dicts_are_refused_before_any_gpu_work():
 
 
 def test_uniform_hash_is_open_interval_and_spread():
-    u = np.array([gumbel_uniform(7, c, r, a) for c in range(4) for r in range(200) for a in range(6)])
+    u = np.array([draw_uniform(7, c, r, a) for c in range(4) for r in range(200) for a in range(6)])
     assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
     assert len(np.unique(u)) > 0.99 * len(u)
 
@@ -220,7 +220,7 @@ def test_uniform_hash_extremes_stay_inside_the_open_interval():
     assert hi.dtype == np.float32 and 0.0 < lo and hi < 1.0 and np.isfinite(np.log(-np.log(hi))) and np.isfinite(np.log(-np.log(lo)))
     # and the library agrees with this formula on real hashes
     for row in range(50):
-        u = gumbel_uniform(3, 5, row, 2)
+        u = draw_uniform(3, 5, row, 2)
         assert 2.0 ** -24 <= u <= 1.0 - 2.0 ** -24
 
 
@@ -432,7 +432,7 @@ def test_sampling_is_the_inverse_cdf_of_the_exported_uniform():
     obs = torch.from_numpy(z["obs"]).cuda()
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[get("a0.")])
     r = _run(nets, 240, [(0, 240, 0, TILE_ACT)], obs, seed=1234, counter=9)
-    u = np.array([gumbel_uniform(1234, 9, row, 0) for row in range(240)], dtype=np.float64)
+    u = np.array([draw_uniform(1234, 9, row, 0) for row in range(240)], dtype=np.float64)
     cum = np.cumsum(np.exp(r["logp"].astype(np.float64)), axis=-1)
     cum /= cum[:, -1:]
     expect = np.minimum((cum <= u[:, None]).sum(-1), 5)
@@ -446,6 +446,75 @@ def test_sampling_is_the_inverse_cdf_of_the_exported_uniform():
     assert np.abs(freq - np.exp(z["a0.logits"][0])).max() < 0.015
     r2 = _run(nets, 240, [(0, 240, 0, TILE_ACT)], obs, seed=1234, counter=10)
     assert (r2["actions"] != r["actions"]).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_a_sampled_action_always_has_positive_mass():
+    """Head biases of -300 on the last three actions: their softmax mass underflows to exactly 0 in f32, so no draw may select them
+    however close the row's uniform is to 1.  (The threshold is u x the last value of the very cumulative chain the comparison runs
+    over; as u x (own + other half's sum) a threshold rounded up to the chain's end used to fall through to action n_out - 1.)
+    Two million draws, every one an action of positive mass, and the law over the three live actions follows their probabilities."""
+    actor = random_net(5, 4, 6, ACTOR_HEAD, 9)
+    actor[ACTOR_HEAD + ".bias"] = np.array([0.3, -0.2, 0.1, -300.0, -300.0, -300.0], np.float32)
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[actor])
+    n = 1 << 21
+    obs = torch.zeros((n, 5, 4, 20), dtype=torch.int8, device="cuda")
+    obs[:, 1, 2, 0] = 1
+    plan = PolicyPlan(nets, n, [(0, n, 0, TILE_ACT)])
+    acts = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    logp = torch.zeros((n, 6), device="cuda")
+    for counter in (0, 1):
+        plan.forward(obs, actions=acts, logp=logp, seed=11, counter=counter)
+        torch.cuda.synchronize()
+        assert int(acts.min()) >= 0 and int(acts.max()) <= 2
+        p = np.exp(logp[0].cpu().numpy())                                 # (f32, as the kernel's own masses: exp(-300) = 0)
+        assert p[3:].max() == 0.0
+        freq = np.bincount(acts.cpu().numpy(), minlength=6) / n
+        assert np.abs(freq - p).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_activation_range_audit_and_saturation():
+    """The dense layers carry hidden activations as f16 pieces at 2^4 x their value: above 65 504 / 16 = 4094 they saturate, where
+    the reference's f32 forward does not (documented in PackedNetworks; the reference's trained networks sit at O(1-100)).  (i) NaN /
+    Inf parameters are refused at pack time; (ii) `activation_range` reports the f32 maxima and flags the overflow; (iii) a network
+    scaled so that its activations reach the thousands but stay under the limit still matches the reference to f32 class (relative to
+    its output scale); (iv) over the limit the outputs are finite and deterministic -- the clamp, not inf - inf."""
+    from diverse_conventions_amd.fused_policy import ACTIVATION_LIMIT
+    rng = np.random.default_rng(4)
+    obs_np = ((rng.random((256, 5, 4, 20)) < 0.15) * rng.integers(1, 21, (256, 5, 4, 20))).astype(np.int8)
+    obs = torch.from_numpy(obs_np).cuda()
+    base = random_net(5, 4, 6, ACTOR_HEAD, 31)
+    bad = dict(base)
+    bad["base.cnn.cnn.3.weight"] = base["base.cnn.cnn.3.weight"].copy()
+    bad["base.cnn.cnn.3.weight"][3, 7] = np.inf
+    with pytest.raises(ValueError, match="non-finite"):
+        PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[bad])
+    nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[base])
+    r0 = nets.activation_range(0, obs)
+    assert not r0["saturates"] and r0["limit"] == ACTIVATION_LIMIT == 4094.0
+    ref = reference_forward(base, obs_np, ACTOR_HEAD)
+    assert abs(r0["out"] - np.abs(ref).max()) < 1e-3 * max(1.0, np.abs(ref).max())
+    # (iii) conv weights and bias x s: conv activations x s, everything behind them x s as well (ReLU is positively homogeneous up to
+    # the later biases) -- choose s so that the largest hidden activation lands at ~3000
+    peak = max(r0["conv"], r0["fc1"], r0["fc2"])
+    big = dict(base)
+    s = np.float32(3000.0 / peak)
+    big["base.cnn.cnn.0.weight"], big["base.cnn.cnn.0.bias"] = base["base.cnn.cnn.0.weight"] * s, base["base.cnn.cnn.0.bias"] * s
+    nets_big = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[big])
+    rb = nets_big.activation_range(0, obs)
+    assert not rb["saturates"] and max(rb["conv"], rb["fc1"], rb["fc2"]) > 1500
+    got = _run(nets_big, 256, [(0, 256, 0, 0)], obs)
+    want = reference_forward(big, obs_np, ACTOR_HEAD)
+    assert np.abs(got["raw"] - want).max() < 4e-6 * max(1.0, np.abs(want).max())
+    # (iv) ten times more: over the limit -- flagged by the audit, finite and repeatable in the kernel
+    huge = dict(big)
+    huge["base.cnn.cnn.0.weight"], huge["base.cnn.cnn.0.bias"] = big["base.cnn.cnn.0.weight"] * 10, big["base.cnn.cnn.0.bias"] * 10
+    nets_huge = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[huge])
+    assert nets_huge.activation_range(0, obs)["saturates"]
+    g1 = _run(nets_huge, 256, [(0, 256, 0, 0)], obs)
+    g2 = _run(nets_huge, 256, [(0, 256, 0, 0)], obs)
+    assert np.isfinite(g1["raw"]).all() and np.array_equal(g1["raw"], g2["raw"])
 
 
 @pytest.mark.gpu

@@ -127,10 +127,10 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
 
 @pytest.mark.gpu
 def test_two_collections_draw_fresh_action_noise(layout_params):
-    """The Gumbel noise of the sampled actions is hash(seed, draw counter + t, row, action): a second collect() with the same
+    """The uniform behind a sampled action is hash(seed, draw counter + t, row, 0): a second collect() with the same
     weights, the same coin flips and the same seed must continue the counter, not replay the first collection's noise."""
     from diverse_conventions_amd import OvercookedEngine, PackedNetworks
-    from diverse_conventions_amd.fused_policy import gumbel_uniform
+    from diverse_conventions_amd.fused_policy import draw_uniform
     from diverse_conventions_amd.mixed_play import MixedPlayRollout
     z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
     pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}
@@ -148,7 +148,7 @@ def test_two_collections_draw_fresh_action_noise(layout_params):
     assert not torch.equal(a1[0], a2[0]), "the second collection replayed the first one's sampling noise"
     assert torch.equal(lp1[0].isfinite(), torch.ones_like(lp1[0], dtype=torch.bool))
     # and the draw of step t of the second collection is the one the exported hash gives for counter 2L + t
-    u_first = np.array([gumbel_uniform(77, 0, r, a) for r in range(4) for a in range(6)])
-    u_second = np.array([gumbel_uniform(77, 2 * L, r, a) for r in range(4) for a in range(6)])
+    u_first = np.array([draw_uniform(77, 0, r, a) for r in range(4) for a in range(6)])
+    u_second = np.array([draw_uniform(77, 2 * L, r, a) for r in range(4) for a in range(6)])
     assert not np.array_equal(u_first, u_second)
     eng.close()
