@@ -25,9 +25,10 @@
  *     SURVEY.md 8(b) "threading").  Several handles per process are fine.
  *   - P = 2 players is the tuned path (the reference's training scripts and its dish-usefulness rule are 2-player): C = 5P+10
  *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
- *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a plain, separate kernel pair with the same buffers and
- *     semantics, C = 5P+10 channels, behind every entry point of this header: where the 2-player path has a single fused launch
- *     (oc_rollout_fused, oc_encode_trajectory, oc_group_step) they run the equivalent sequence of plain launches, same results.
+ *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a kernel of their own (csrc/oc_np_kernels.h: ONE launch per
+ *     step as well, records included) with the same buffers and semantics, C = 5P+10 channels, behind every entry point of this
+ *     header: where the 2-player path has a single launch for SEVERAL steps or engines (oc_rollout_fused, oc_encode_trajectory,
+ *     oc_group_step) they run the equivalent sequence of per-step / per-engine launches, same results.
  *     Only the fused policy kernel (overcooked_ops.h) reads 2-player observations only.  S = width*height <= 255 tiles.
  *
  * Tensor layouts (identical in meaning to the reference's exported tensors)
@@ -211,7 +212,8 @@ int oc_device_id(const oc_engine *e);
 
 /* Launch tuning (performance only, results never change): kitchens per wavefront group (1..64;
  * kitchens*tiles must be a multiple of 4, so any multiple of 4 works), 64-tile staging passes per flush (1..8), persistent wavefronts per CU (1..32).
- * 0 keeps the current value. */
+ * 0 keeps the current value.  Engines with 1, 3 or 4 players: kitchens per group (x players <= 64, x 16-byte chunks per record
+ * <= 256), passes per flush (1..8), wavefronts per CU (1..32); until it is called their launches choose a geometry per batch size. */
 int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int waves_per_cu);
 
 /* Build NOW what is otherwise compiled on first use -- the step kernels for fresh (time-major) destinations and the

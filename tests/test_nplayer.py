@@ -1,6 +1,6 @@
 """Kitchens with 1, 3 and 4 players (the reference's Python MDP and encoder are N-player: envs/overcooked2_reimplement.py
 :221-234, :261-263; envs/overcooked2_env.py:29 `num_players`; layouts multiplayer_schelling, simple_single).  The HIP engine
-runs them on a plain kernel pair (csrc/oc_np_kernels.h); parity bar as everywhere: bit-exact against fixtures recorded from the
+runs them on the group kernel of csrc/oc_np_kernels.h (one launch per step since round 5); parity bar as everywhere: bit-exact against fixtures recorded from the
 reference (tests/golden/np_*.npz, make_golden_nplayer.py) and against the oracle on batches."""
 import json
 import os
@@ -80,6 +80,45 @@ def test_hip_vs_oracle_nplayer_batch(case):
     eng.step(dacts[0]); twin.step(dacts[0])
     assert torch.equal(twin.obs, eng.obs) and torch.equal(twin.export_states(), eng.export_states())
     eng.close(); twin.close()
+
+
+@pytest.mark.parametrize("case,n", [("schelling4", 36001), ("schelling3", 33001), ("single", 70003)])
+def test_nplayer_large_batches_and_launch_geometries(case, n):
+    """Batches large enough for the 16-kitchen groups of the N-player kernel (persistent wavefronts walk several groups, the next
+    group's records prefetched), odd kitchen counts (ragged last group; with three players every viewer plane but the first starts
+    off a dword: 1..3 single bytes, then 16-byte stores of LDS reads at that byte offset), against the oracle with records; then the
+    same steps under other launch geometries (oc_set_tuning: kitchens per group, passes per flush, wavefronts per CU) must give
+    identical bytes."""
+    from diverse_conventions_amd import OvercookedEngine
+    params = dict(nplayer_params()[case], horizon=7)
+    P, T = params["num_players"], 10
+    rng = np.random.default_rng(n)
+    acts = rng.integers(0, 6, size=(T, P, n)).astype(np.int32)
+    acts[:, :, ::3] = 5                                                # a third of the kitchens interact all the time
+    dacts = torch.from_numpy(acts).cuda()
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng = OvercookedEngine(params, n, 0)
+    recs = torch.zeros((T, n, eng.record_bytes // 4), dtype=torch.int32, device="cuda")
+    want_obs = []
+    for t in range(T):
+        obs, rew, done = eng.step(dacts[t], records=recs[t])
+        oobs, orew, odone = ora.step(acts[t])
+        assert np.array_equal(obs.cpu().numpy(), oobs), t
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy(), odone), t
+        assert torch.equal(recs[t], eng.export_states()), t
+        want_obs.append(obs.clone())
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    eng.close()
+    recq = eng.record_bytes // 16                                      # (a group's records fit the prefetch window: K x recq <= 256 chunks)
+    for K, G, w in ((16 if P > 1 else 32, 3, 8), (5, 1, 3), (min(64 // P, 256 // recq), 4, 2), (1, 2, 32)):
+        e2 = OvercookedEngine(params, n, 0)
+        e2.set_tuning(K, G, w)
+        for t in range(T):
+            obs, _, _ = e2.step(dacts[t])
+            assert torch.equal(obs, want_obs[t]), (K, G, w, t)
+        assert torch.equal(e2.export_states(), recs[T - 1])
+        e2.close()
 
 
 def test_four_player_drop_in_env_and_buffers():

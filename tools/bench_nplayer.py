@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""us per step of the plain N-player kernel pair (csrc/oc_np_kernels.h): multiplayer_schelling with 4 and 3 players,
+"""us per step of the N-player group kernel (csrc/oc_np_kernels.h; rounds 2-4: a plain kernel pair): multiplayer_schelling with 4 and 3 players,
 simple_single, at 65 536 and 8192 kitchens, outputs in place.  Bytes per kitchen-step: P*S*(5P+10) obs + 2*record + 4P
 actions + 4P reward + 4 done."""
 import json, os, sys
