@@ -556,10 +556,12 @@ def main():
           step_modes = {}
           ro.step(SEC_WARMUP)
           torch.cuda.synchronize()
-          t1 = time.perf_counter()
-          ro.step(psteps)
-          torch.cuda.synchronize()
-          step_modes["two_launches"] = (time.perf_counter() - t1) / psteps * 1e6
+          step_modes["two_launches"] = float("inf")
+          for _ in range(2):                             # (best of two, as for the share leg below)
+              t1 = time.perf_counter()
+              ro.step(psteps)
+              torch.cuda.synchronize()
+              step_modes["two_launches"] = min(step_modes["two_launches"], (time.perf_counter() - t1) / psteps * 1e6)
           step_us = step_modes["two_launches"]
           # ... and what training does: the same two launches per step, every step's planes into their own time-major slot
           # (TrajectoryBuffer; the fresh planes are stored plainly while the rollout runs -- the next launch reads them)
@@ -617,10 +619,12 @@ def main():
           ro3 = FusedPairedRollout(eng3, nets3, sthreads, sk, critic_nets=[[sk + 1 + g for g in range(sG)]] * 2)
           ro3.step(SEC_WARMUP)
           torch.cuda.synchronize()
-          t3 = time.perf_counter()
-          ro3.step(SEC_STEPS)
-          torch.cuda.synchronize()
-          share_us = (time.perf_counter() - t3) / SEC_STEPS * 1e6
+          share_us = float("inf")
+          for _ in range(2):                             # (best of two: 2 x SEC_STEPS launches of ~20 us each are enqueued by the host as they run,
+              t3 = time.perf_counter()                   #  and a descheduled host thread shows up as GPU idle time -- one driver-style run read 79.8 us)
+              ro3.step(SEC_STEPS)
+              torch.cuda.synchronize()
+              share_us = min(share_us, (time.perf_counter() - t3) / SEC_STEPS * 1e6)
           share = {"what": f"BASELINE config 4, one GPU's share of 8: asymmetric_advantages, {eng3.num_kitchens} kitchens, {sk + 1} conventions in {sG} "
                            f"pairing segments of {sthreads} kitchens, every actor and one critic per segment on both sides in ONE fused MFMA launch "
                            "per step + the env launch, all steps enqueued by one call; random-weight reference-shape networks",
