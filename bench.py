@@ -664,6 +664,30 @@ def main():
                            "K-steps-per-launch rollout has no launch boundary per step"}
         eng_c2.close()
 
+    # Secondary figure, never `value`: kitchens with other player counts (the reference's `num_players`: multiplayer_schelling with 4 and 3
+    # players, simple_single), one launch per step on the N-player group kernel (csrc/oc_np_kernels.h), outputs in place
+    nplayer = None
+    if world == 1 and not args.no_secondary:
+      try:
+          nplayer = {"what": "kitchens with 4 / 3 / 1 players (multiplayer_schelling, simple_single), 65536 kitchens, one launch per step "
+                             "(transition + encoding of every viewer), outputs in place; bytes per kitchen-step = P*S*(5P+10) obs + 2 records + 4P actions + 4P reward + 4 done",
+                     "steps": SEC_STEPS // 2, "cases": []}
+          for np_layout, np_max in (("multiplayer_schelling", None), ("multiplayer_schelling", 3), ("simple_single", None)):
+              npp = get_base_layout_params(np_layout, 200, max_num_players=np_max)
+              nP, nS, nn = npp["num_players"], npp["width"] * npp["height"], 65536
+              eng_np = OvercookedEngine(npp, nn, local)
+              act_np = torch.randint(0, 6, (t_act, nP, nn), generator=gen, device="cuda", dtype=torch.int32)
+              eng_np.rollout(act_np, 50)
+              np_us = min(eng_np.rollout_timed(act_np, SEC_STEPS // 2) for _ in range(2)) * 1e3 / (SEC_STEPS // 2)
+              np_bytes = nn * (nP * nS * (5 * nP + 10) + 2 * eng_np.record_bytes + 8 * nP + 4)
+              nplayer["cases"].append({"layout": np_layout, "players": nP, "kitchens": nn, "us_per_launch": np_us, "value": nP * nn / np_us * 1e6,
+                                       "unit": "agent-env steps/s", "bytes_per_launch": np_bytes, "achieved_GBps": np_bytes / np_us / 1e3,
+                                       "frac_of_8TBps": np_bytes / np_us / 1e3 / HBM_PEAK_GBS, "kernel_build": eng_np.kernel_build_info})
+              eng_np.close()
+              del act_np
+      except Exception as exc:                             # noqa: BLE001
+        nplayer = {"error": f"{type(exc).__name__}: {exc}"}
+
     # Secondary figure, never `value`: the mixed-play collection: 329 x 199 = 65 471 kitchens, two episodes of
     # L = 200 steps, per step ONE gathered policy launch (every row evaluated once, by the network the coin gave it) + the env
     # launch, all 2L steps enqueued by one call; checked: sampled kitchens replayed through the CPU oracle with the recorded actions
@@ -789,6 +813,8 @@ def main():
             out["fused_rollout"] = fused
         if config2 is not None:
             out["config2"] = config2
+        if nplayer is not None:
+            out["nplayer"] = nplayer
         if mixed is not None:
             out["mixed_play"] = mixed
         if policy is not None:
