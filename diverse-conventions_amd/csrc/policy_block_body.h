@@ -186,6 +186,15 @@
         }
         if (traced) stamp(a, wave, lane, 4);
         if (traced2) stamp(a, wave, lane, 26);
+        // (diagnostics build, timing only -- outputs are then missing: OC_POLICY_DESYNC = -3 ends the block here, -2 behind fc2, -1 behind
+        // the head: what the dense tail and the epilogue cost the launch, tools/exp_policy_stagger.py)
+        if (kPolicyTrace && a.desync == -3) {
+            wave_lds_sync();
+            const int nxt3 = cp ? -1 : blk + nwaves < last_full ? blk + nwaves : leader ? last_full + grp : -1;
+            if (nxt3 >= 0) stage(nxt3);
+            if (h1[0][0] == 12345.678f) S.logp[0] = h1[1][3];          // (keeps the position loop's results alive)
+            continue;
+        }
         v16f h2[2], out, out2;
         {
             const v4f *bq = reinterpret_cast<const v4f *>(b2);
@@ -260,6 +269,7 @@
         }
         if (traced) stamp(a, wave, lane, 5);
         if (traced2) stamp(a, wave, lane, 28);
+        if (kPolicyTrace && a.desync == -2) { if (h2[0][0] == 12345.678f) S.logp[0] = h2[1][3]; continue; }
         // ---- head: out^T[a][row], a = reg + 4h for reg 0..3; two accumulators so consecutive MFMAs do not wait for each other ----
         {
             v4i gb[2][kPieces];
@@ -281,6 +291,7 @@
         }
         if (traced) stamp(a, wave, lane, 6);
         if (traced2) stamp(a, wave, lane, 29);
+        if (kPolicyTrace && a.desync == -1) { if (out[0] == 12345.678f) S.logp[0] = out[1]; continue; }
 
         // ---- epilogue.  Lane (col, h) holds outputs a = 4h + r (r = 0..3) of row `col`: the two halves of a row
         //      work on their own actions and meet through three lane exchanges ----

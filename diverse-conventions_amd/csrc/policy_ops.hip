@@ -855,7 +855,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
         loaded_net = net;
         loaded_slot = cur_slot;
         stamp(a, wave, lane, 1);
-        if (a.desync && wave >= 4)                                    // experiment: break the lock-step of a SIMD's two waves
+        if (a.desync > 0 && wave >= 4)                                // experiment: break the lock-step of a SIMD's two waves
             for (int i = 0; i < a.desync; i += 100) __builtin_amdgcn_s_sleep(100);
     }
 
