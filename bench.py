@@ -419,8 +419,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
-    barrier()
-    wall = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0                      # this rank's K steps: from behind the opening barrier + sync to its own sync; MAX over ranks below
+    barrier()                                            # (the closing barrier: behind the clock -- with N ranks it is an all-reduce whose own latency,
+                                                         #  tens of microseconds, is not part of the K steps a 20-step run times)
     fused_ms = tm_us = c4_wall = c4_kernel_ms = float("nan")
     slots, c4_total, c4_n, c4_S, c4_steps, c3 = 64, 65536, 65536 // world, 45, SEC_STEPS, None
     if not args.no_secondary:
@@ -470,8 +472,9 @@ def main():
         barrier()
         t4 = time.perf_counter()
         c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
-        barrier()
+        torch.cuda.synchronize()
         c4_wall = time.perf_counter() - t4
+        barrier()
         eng4.close()
 
         # Secondary figure, never `value`: BASELINE config 3's env step -- the five classic layouts x 8192 kitchens stepped by
@@ -785,6 +788,8 @@ def main():
             "value": 2 * n * world * args.steps / wall,
             "unit": "agent-env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "launcher": launcher,
+            "timing": "per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; ms_per_step and value from the MAX over ranks",
+
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
