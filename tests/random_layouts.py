@@ -42,3 +42,28 @@ def busy_actions(rng, T, n):
     a = rng.integers(0, 6, size=(T, 2, n))
     a[rng.random((T, 2, n)) < 0.25] = 5
     return a.astype(np.int32)
+
+
+def random_layout_players(rng, players, max_w=10, max_h=7):
+    """The same kitchens with 1, 3 or 4 players: `random_layout` (its random stream untouched, so the 2-player seeds keep their
+    kitchens), then the first start dropped or further distinct free tiles drawn as start positions."""
+    while True:
+        p = random_layout(rng, max_w, max_h)
+        W, H = p["width"], p["height"]
+        starts = list(zip(p["start_player_y"], p["start_player_x"]))
+        free = [(y, x) for y in range(1, H - 1) for x in range(1, W - 1) if p["terrain"][y * W + x] == 0 and (y, x) not in starts]
+        if players > 2 and len(free) < players - 2:
+            continue
+        if players < 2:
+            starts = starts[:players]
+        else:
+            extra = rng.choice(len(free), size=players - 2, replace=False) if players > 2 else []
+            starts += [free[int(i)] for i in extra]
+        p = dict(p, num_players=players, start_player_x=[int(s[1]) for s in starts], start_player_y=[int(s[0]) for s in starts])
+        return p
+
+
+def busy_actions_players(rng, T, players, n):
+    a = rng.integers(0, 6, size=(T, players, n))
+    a[rng.random((T, players, n)) < 0.25] = 5
+    return a.astype(np.int32)
