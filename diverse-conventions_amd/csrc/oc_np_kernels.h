@@ -42,6 +42,9 @@ struct NpArgs {
     uint32_t start_pp[kMaxP];
     uint32_t *rec_out;              // the post-step (STEP) / the featurised (!STEP) records also go here ([N][recd], 16-byte aligned: the trajectory's slot); NULL: not recorded
     int32_t K, G;                   // launch geometry: kitchens per group, passes of 64 tiles per flush (NpGeom)
+    // batched featurisation (!STEP: oc_encode_trajectory): `items` blocks of n records each, item b at state + b * state_item_stride
+    // (dwords) with its planes at obs + b * obs_item_stride (bytes); groups run over all items.  1 item otherwise.
+    int64_t items, state_item_stride, obs_item_stride;
     int32_t no_pipeline;            // diagnostics: records loaded at the head of each group instead of one group ahead
     float inv_S, inv_H, inv_W, inv_recq;   // 1 / S ...: quotients of the small indices below as (x + 0.5) * inv (np_div; exact there)
 };
@@ -97,25 +100,28 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     int8_t *const l_stage = reinterpret_cast<int8_t *>(np_lds + np_lds_fixed_dwords(S, recd, K));    // [P][G * 64 * C]
     const int vstride = G * 64 * C;                        // bytes of one viewer's staging range (a multiple of 64)
 
-    const int64_t n_groups = (a.n + K - 1) / K;
+    const int64_t groups_per_item = (a.n + K - 1) / K, n_groups = groups_per_item * a.items;
+    // group -> (item, first kitchen inside the item); one item unless a whole trajectory is featurised by one launch
+    auto item_of = [&](int64_t g) { return a.items > 1 ? g / groups_per_item : static_cast<int64_t>(0); };
     // ---- software pipeline: registers hold the NEXT group's records and actions while this one is stepped and encoded (the loads
     //      are unconditional, indices clamped into the arrays, so that they land in these registers and are waited for only where
     //      the loop says so -- before a group's first plane store: vmcnt retires in order, a later wait would sit behind the stores)
     constexpr int kNpQ = 4;                                // 16-byte chunks per lane: K * recq <= 256 (np_geometry)
     u32x4 pre[kNpQ];
     int pa[P];
-    const bool aligned = (reinterpret_cast<uintptr_t>(a.state) & 15) == 0 && !a.no_pipeline;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.state) & 15) == 0 && (a.state_item_stride & 3) == 0 && !a.no_pipeline;
     // (clamped to the GROUP's own chunks: lanes past them re-read its last one.  Clamped to the array's end instead they read the
     // following groups' records -- 2.7 x the bytes with sixteen 96-byte records per group, and lines their owners are writing back:
     // 65 536 one-player kitchens 18.3 against 15.3 us per step, tools/ab_nplayer.py)
     auto prefetch = [&](int64_t g) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.state) + g * K * recq;
-        const int nkg = static_cast<int>(min(static_cast<int64_t>(K), a.n - g * K));
+        const int64_t item = item_of(g), gi = g - item * groups_per_item;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.state + item * a.state_item_stride) + gi * K * recq;
+        const int nkg = static_cast<int>(min(static_cast<int64_t>(K), a.n - gi * K));
         const int room = nkg * recq - 1;
 #pragma unroll
         for (int q = 0; q < kNpQ; ++q) pre[q] = src[min(lane + q * 64, room)];
         if (STEP) {
-            const int64_t k = g * K + min(lane, nkg - 1);
+            const int64_t k = gi * K + min(lane, nkg - 1);       // (STEP launches have one item)
 #pragma unroll
             for (int i = 0; i < P; ++i)
                 pa[i] = a.act64 ? static_cast<int>(reinterpret_cast<const long long *>(a.actions)[i * a.n + k])
@@ -142,8 +148,11 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     wave_sync();
 
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const int64_t k0 = g * K;
+        const int64_t item = item_of(g);
+        const int64_t k0 = (g - item * groups_per_item) * K;
         const int nk = static_cast<int>(min(static_cast<int64_t>(K), a.n - k0));
+        const uint32_t *const item_state = a.state + item * a.state_item_stride;
+        int8_t *const item_obs = a.obs + item * a.obs_item_stride;
         int raw[P];
         if (aligned) {
             // ---- prefetched records -> LDS, then start fetching the next group
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
                     raw[i] = a.act64 ? static_cast<int>(reinterpret_cast<const long long *>(a.actions)[i * a.n + k0 + lane])
                                      : reinterpret_cast<const int *>(a.actions)[i * a.n + k0 + lane];
             }
-            const uint32_t *src = a.state + k0 * recd;
+            const uint32_t *src = item_state + k0 * recd;
             for (int c = lane; c < nk * recd; c += 64) {
                 const int k = np_div(c >> 2, a.inv_recq);
                 l_state[k * lstride + (c - k * recd)] = src[c];
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
             const int nbytes = wtiles * C;
 #pragma unroll
             for (int v = 0; v < P; ++v) {
-                int8_t *dst = a.obs + v * a.obs_player_stride + plane0 + static_cast<int64_t>(f0) * C;
+                int8_t *dst = item_obs + v * a.obs_player_stride + plane0 + static_cast<int64_t>(f0) * C;
                 const int8_t *src = l_stage + v * vstride;
                 // 16-byte stores need a dword-aligned destination only (store16).  A plane that starts off a dword (odd C -- one or
                 // three players -- behind an odd number of kitchens x tiles) gets its first 1..3 bytes singly and the rest as 16-byte

@@ -27,8 +27,9 @@
  *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
  *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a kernel of their own (csrc/oc_np_kernels.h: ONE launch per
  *     step as well, records included) with the same buffers and semantics, C = 5P+10 channels, behind every entry point of this
- *     header: where the 2-player path has a single launch for SEVERAL steps or engines (oc_rollout_fused, oc_encode_trajectory,
- *     oc_group_step) they run the equivalent sequence of per-step / per-engine launches, same results.
+ *     header (oc_encode_trajectory included: one launch for a whole trajectory): where the 2-player path has a single launch for
+ *     SEVERAL steps or engines (oc_rollout_fused, oc_group_step) they run the equivalent sequence of per-step / per-engine launches,
+ *     same results.
  *     Only the fused policy kernel (overcooked_ops.h) reads 2-player observations only.  S = width*height <= 255 tiles.
  *
  * Tensor layouts (identical in meaning to the reference's exported tensors)

@@ -121,6 +121,37 @@ def test_nplayer_large_batches_and_launch_geometries(case, n):
         e2.close()
 
 
+@pytest.mark.parametrize("case,n", [("schelling3", 1003), ("schelling4", 5000), ("single", 777)])
+def test_nplayer_trajectory_featurised_by_one_launch(case, n):
+    """oc_encode_trajectory with 1, 3, 4 players: ONE launch of the group kernel over all T blocks of records (a launch per time step
+    before round 5) -- strided record blocks (every other slot of a larger tensor), written at a kitchen offset inside a wider
+    [T, P, N_total, W, H, C] tensor whose planes then start off 16-byte (three players: off dword) boundaries, the rest of the tensor
+    untouched; against per-step oc_encode_states of the same records, and one block that is only dword aligned."""
+    from diverse_conventions_amd import OvercookedEngine
+    params = dict(nplayer_params()[case], horizon=9)
+    P, T = params["num_players"], 7
+    eng = OvercookedEngine(params, n, 0)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    big = torch.zeros((2 * T, n, eng.record_bytes // 4), dtype=torch.int32, device="cuda")
+    for t in range(T):
+        eng.step(torch.randint(0, 6, (P, n), device="cuda", dtype=torch.int32, generator=g), records=big[2 * t])
+    recs = big[::2]                                                     # [T, n, rec/4], block stride 2 x n x rec
+    want = torch.stack([eng.encode_states(recs[t].contiguous()) for t in range(T)])            # [T, P, n, W, H, C]
+    off, n_total = 3, n + 8
+    out = torch.full((T, P, n_total) + tuple(want.shape[3:]), 77, dtype=torch.int8, device="cuda")
+    eng.encode_trajectory_into(recs, out, off)
+    assert torch.equal(out[:, :, off:off + n], want)
+    assert bool((out[:, :, :off] == 77).all()) and bool((out[:, :, off + n:] == 77).all())
+    # a record block that starts 4 bytes off a 16-byte boundary (the pipeline's 16-byte loads do not apply: dword loads)
+    flat = torch.zeros(recs[0].numel() + 1, dtype=torch.int32, device="cuda")
+    flat[1:] = recs[T - 1].reshape(-1)
+    assert flat[1:].data_ptr() % 16 == 4
+    one = torch.zeros((1, P, n) + tuple(want.shape[3:]), dtype=torch.int8, device="cuda")
+    eng.encode_trajectory_into(flat[1:].view(1, n, -1), one, 0)
+    assert torch.equal(one[0], want[T - 1])
+    eng.close()
+
+
 def test_four_player_drop_in_env_and_buffers():
     """OvercookedMadrona("multiplayer_schelling", ...) as the reference constructs it (envs/overcooked2_env.py:29): three partner
     agents, observations (N, 7, 7, 30); the time-major TrajectoryBuffer, per-kitchen episode control and state export / import /
