@@ -45,6 +45,11 @@ struct NpArgs {
     // batched featurisation (!STEP: oc_encode_trajectory): `items` blocks of n records each, item b at state + b * state_item_stride
     // (dwords) with its planes at obs + b * obs_item_stride (bytes); groups run over all items.  1 item otherwise.
     int64_t items, state_item_stride, obs_item_stride;
+    // K steps per launch (STEP: oc_rollout_fused): a group's records stay in LDS for n_steps steps; step t reads action slice
+    // t % tape_steps of a tape of [P][N] slices and writes obs + t * obs_step_stride (bytes; 0 = in place), reward + t * reward_step_stride,
+    // done + t * done_step_stride (elements), rec_out + t * rec_step_stride (dwords).  n_steps = 1 otherwise.
+    int32_t n_steps, tape_steps;
+    int64_t obs_step_stride, reward_step_stride, done_step_stride, rec_step_stride;
     int32_t no_pipeline;            // diagnostics: records loaded at the head of each group instead of one group ahead
     float inv_S, inv_H, inv_W, inv_recq;   // 1 / S ...: quotients of the small indices below as (x + 0.5) * inv (np_div; exact there)
 };
@@ -83,11 +88,18 @@ __host__ __device__ inline size_t np_lds_bytes(int S, int P, int recd, NpGeom g)
     return static_cast<size_t>(np_lds_fixed_dwords(S, recd, g.K)) * 4 + static_cast<size_t>(P) * g.G * 64 * (5 * P + 10);
 }
 
-template <int P, bool STEP, int SM>
+template <int P, bool STEP, int SM, bool FUSED = false, bool BATCH = false>
 __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t np_lds[];
     constexpr int C = 5 * P + 10, shift = 5 * P;
     const int lane = static_cast<int>(threadIdx.x);
+    // Every kernel argument the wavefront will use, asked for at once: left alone the compiler loads each field next to its first use,
+    // one scalar-memory round trip after the other in front of the first memory request (five of them in one build: +0.5 us per launch
+    // on every shape -- 5.5 -> 6.1 us at 8192 one-player kitchens; seen in the listing, as for the 2-player kernel in round 3).
+    asm volatile("" : : "s"(a.state), "s"(a.terrain), "s"(a.actions), "s"(a.obs), "s"(a.reward), "s"(a.done), "s"(a.rec_out), "s"(a.n),
+                 "s"(a.obs_player_stride), "s"(a.S), "s"(a.W), "s"(a.H), "s"(a.recd), "s"(a.K), "s"(a.G), "s"(a.act64));
+    asm volatile("" : : "s"(a.horizon), "s"(a.placement_rew), "s"(a.soup_rew), "s"(a.inv_S), "s"(a.inv_H), "s"(a.inv_W), "s"(a.inv_recq),
+                 "s"(a.no_pipeline), "s"(a.items), "s"(a.state_item_stride), "s"(a.obs_item_stride), "s"(a.n_steps), "s"(a.tape_steps));
     const int S = a.S, W = a.W, H = a.H, recd = a.recd, recq = recd >> 2, K = a.K, G = a.G;
     const int lstride = np_lstride(recd);
     uint32_t *const l_terr = np_lds;                       // [S] terrain code of state tile t
@@ -100,9 +112,11 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     int8_t *const l_stage = reinterpret_cast<int8_t *>(np_lds + np_lds_fixed_dwords(S, recd, K));    // [P][G * 64 * C]
     const int vstride = G * 64 * C;                        // bytes of one viewer's staging range (a multiple of 64)
 
-    const int64_t groups_per_item = (a.n + K - 1) / K, n_groups = groups_per_item * a.items;
-    // group -> (item, first kitchen inside the item); one item unless a whole trajectory is featurised by one launch
-    auto item_of = [&](int64_t g) { return a.items > 1 ? g / groups_per_item : static_cast<int64_t>(0); };
+    const int64_t groups_per_item = (a.n + K - 1) / K, n_groups = BATCH ? groups_per_item * a.items : groups_per_item;
+    // group -> (item, first kitchen inside the item); one item unless a whole trajectory is featurised by one launch (BATCH: a build of
+    // its own -- behind a run-time test the compiler still issued the 64-bit division for every group: 12.8 -> 13.5 us per step at
+    // 65 536 one-player kitchens)
+    auto item_of = [&](int64_t g) { return BATCH ? static_cast<int64_t>(static_cast<uint32_t>(g) / static_cast<uint32_t>(groups_per_item)) : static_cast<int64_t>(0); };
     // ---- software pipeline: registers hold the NEXT group's records and actions while this one is stepped and encoded (the loads
     //      are unconditional, indices clamped into the arrays, so that they land in these registers and are waited for only where
     //      the loop says so -- before a group's first plane store: vmcnt retires in order, a later wait would sit behind the stores)
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     // 65 536 one-player kitchens 18.3 against 15.3 us per step, tools/ab_nplayer.py)
     auto prefetch = [&](int64_t g) {
         const int64_t item = item_of(g), gi = g - item * groups_per_item;
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.state + item * a.state_item_stride) + gi * K * recq;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(BATCH ? a.state + item * a.state_item_stride : a.state) + gi * K * recq;
         const int nkg = static_cast<int>(min(static_cast<int64_t>(K), a.n - gi * K));
         const int room = nkg * recq - 1;
 #pragma unroll
@@ -151,8 +165,8 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
         const int64_t item = item_of(g);
         const int64_t k0 = (g - item * groups_per_item) * K;
         const int nk = static_cast<int>(min(static_cast<int64_t>(K), a.n - k0));
-        const uint32_t *const item_state = a.state + item * a.state_item_stride;
-        int8_t *const item_obs = a.obs + item * a.obs_item_stride;
+        const uint32_t *const item_state = BATCH ? a.state + item * a.state_item_stride : a.state;
+        int8_t *const item_obs = BATCH ? a.obs + item * a.obs_item_stride : a.obs;
         int raw[P];
         if (aligned) {
             // ---- prefetched records -> LDS, then start fetching the next group
@@ -184,6 +198,25 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
             }
         }
         wave_sync();
+
+      // K steps per launch: the whole rollout of this group happens here, its records never leave LDS between steps
+      // (FUSED: a build of its own -- as a runtime loop of one iteration it cost the one-step launches 5-20 %, 12.8 -> 14.0 us at
+      // 65 536 one-player kitchens)
+      const int n_steps = FUSED ? a.n_steps : 1;
+      for (int step = 0; step < n_steps; ++step) {
+        int raw_next[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) raw_next[i] = A_STAY;
+        if (FUSED && step + 1 < n_steps && lane < nk) {       // the next step's actions: in flight during this step
+            const int64_t slice = static_cast<int64_t>((step + 1) % a.tape_steps) * P * a.n;
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+                raw_next[i] = a.act64 ? static_cast<int>(reinterpret_cast<const long long *>(a.actions)[slice + i * a.n + k0 + lane])
+                                      : reinterpret_cast<const int *>(a.actions)[slice + i * a.n + k0 + lane];
+        }
+        int8_t *const step_obs = FUSED ? item_obs + step * a.obs_step_stride : item_obs;
+        int32_t *const step_reward = FUSED ? a.reward + step * a.reward_step_stride : a.reward;
+        int32_t *const step_done = FUSED ? a.done + step * a.done_step_stride : a.done;
 
         // ---- phase T: lane = kitchen
         if (lane < nk) {
@@ -263,10 +296,10 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
                     const int np_ = blocked ? pos[i] : npos[i];
                     rec[S + i] = is_done ? a.start_pp[i] : (static_cast<uint32_t>(np_) | (static_cast<uint32_t>(nori[i]) << 8));
                     rec[S + P + i] = is_done ? 0u : held[i];
-                    a.reward[i * a.n + k] = reward;                                              // sum, to every player (overcooked2_env.py:336-339)
+                    step_reward[i * a.n + k] = reward;                                           // sum, to every player (overcooked2_env.py:336-339)
                 }
                 rec[S + 2 * P] = is_done ? 0u : static_cast<uint32_t>(ts);
-                a.done[k] = static_cast<int32_t>(is_done);
+                step_done[k] = static_cast<int32_t>(is_done);
             }
             l_done[lane] = is_done;
         }
@@ -359,12 +392,12 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
                 }
             }
             wave_sync();
-            if (f0 == 0) land_prefetch();                              // the next group's loads: waited for here, in front of this group's first store
+            if (f0 == 0 && step == 0) land_prefetch();                 // the next group's loads: waited for here, in front of this group's first store
             // ---- flush: contiguous bytes of every viewer's plane
             const int nbytes = wtiles * C;
 #pragma unroll
             for (int v = 0; v < P; ++v) {
-                int8_t *dst = item_obs + v * a.obs_player_stride + plane0 + static_cast<int64_t>(f0) * C;
+                int8_t *dst = step_obs + v * a.obs_player_stride + plane0 + static_cast<int64_t>(f0) * C;
                 const int8_t *src = l_stage + v * vstride;
                 // 16-byte stores need a dword-aligned destination only (store16).  A plane that starts off a dword (odd C -- one or
                 // three players -- behind an odd number of kitchens x tiles) gets its first 1..3 bytes singly and the rest as 16-byte
@@ -388,19 +421,26 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
             wave_sync();                                               // the next window overwrites the staging ranges
         }
 
-        // ---- records LDS -> HBM (the engine's block: the next launch's input) and -> the trajectory's record slot
-        if (STEP || a.rec_out) {
+        // ---- records LDS -> the trajectory's record slot of this step, and after the last step -> HBM (the engine's block: the next
+        //      launch's input)
+        const bool last_step = step + 1 == n_steps;
+        if ((STEP && last_step) || a.rec_out) {
             uint4 *dst = reinterpret_cast<uint4 *>(a.state) + k0 * recq;
-            uint4 *rdst = a.rec_out ? reinterpret_cast<uint4 *>(a.rec_out) + k0 * recq : nullptr;
+            uint4 *rdst = a.rec_out ? reinterpret_cast<uint4 *>(FUSED ? a.rec_out + step * a.rec_step_stride : a.rec_out) + k0 * recq : nullptr;
             for (int c = lane; c < nk * recq; c += 64) {
                 const int k = np_div(c, a.inv_recq), j = c - k * recq;
                 const uint32_t *sp = l_state + k * lstride + 4 * j;
                 const uint4 v = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-                if (STEP) dst[c] = v;
+                if (STEP && last_step) dst[c] = v;
                 if (rdst) rdst[c] = v;
             }
         }
-        wave_sync();                                                   // the next group overwrites the LDS records
+        if (FUSED) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) raw[i] = raw_next[i];
+        }
+        wave_sync();                                                   // the next step / group overwrites staging and the LDS records
+      }   // step loop
     }
 }
 

@@ -27,8 +27,8 @@
  *     = 20 channels.  P = 1, 3 or 4 (the reference's Python MDP and encoder are N-player: layouts simple_single,
  *     multiplayer_schelling; OvercookedMadrona(..., num_players)) run on a kernel of their own (csrc/oc_np_kernels.h: ONE launch per
  *     step as well, records included) with the same buffers and semantics, C = 5P+10 channels, behind every entry point of this
- *     header (oc_encode_trajectory included: one launch for a whole trajectory): where the 2-player path has a single launch for
- *     SEVERAL steps or engines (oc_rollout_fused, oc_group_step) they run the equivalent sequence of per-step / per-engine launches,
+ *     header -- oc_encode_trajectory (one launch for a whole trajectory) and oc_rollout_fused with a tape (one launch for T steps,
+ *     records resident on chip) included; only oc_group_step runs a group that contains such engines as one launch per engine,
  *     same results.
  *     Only the fused policy kernel (overcooked_ops.h) reads 2-player observations only.  S = width*height <= 255 tiles.
  *

@@ -110,6 +110,22 @@ def test_nplayer_large_batches_and_launch_geometries(case, n):
     for x, y in zip(eng.get_state(), ora.get_state()):
         assert np.array_equal(x, y)
     eng.close()
+    # the same T steps as ONE launch (oc_rollout_fused: records resident in LDS between the steps), time-major outputs with records
+    e1 = OvercookedEngine(params, n, 0)
+    o1 = torch.zeros((T,) + tuple(e1.obs.shape), dtype=torch.int8, device="cuda")
+    r1, d1 = torch.zeros((T, P, n), dtype=torch.int32, device="cuda"), torch.zeros((T, n), dtype=torch.int32, device="cuda")
+    rec1 = torch.zeros_like(recs)
+    e1.rollout_fused(T, actions=dacts, obs=o1, reward=r1, done=d1, records=rec1)
+    assert torch.equal(o1, torch.stack(want_obs)) and torch.equal(rec1, recs) and torch.equal(e1.export_states(), recs[T - 1])
+    assert int(d1.sum()) > 0                                            # the horizon was crossed inside the launch
+    # ... and in place with a tape shorter than the rollout (slices reused modulo its length)
+    e1.reset_all()
+    e1.rollout_fused(T, actions=dacts[:3].contiguous())
+    e3 = OvercookedEngine(params, n, 0)
+    for t in range(T):
+        e3.step(dacts[t % 3])
+    assert torch.equal(e1.obs, e3.obs) and torch.equal(e1.reward, e3.reward) and torch.equal(e1.done, e3.done) and torch.equal(e1.export_states(), e3.export_states())
+    e1.close(); e3.close()
     recq = eng.record_bytes // 16                                      # (a group's records fit the prefetch window: K x recq <= 256 chunks)
     for K, G, w in ((16 if P > 1 else 32, 3, 8), (5, 1, 3), (min(64 // P, 256 // recq), 4, 2), (1, 2, 32)):
         e2 = OvercookedEngine(params, n, 0)
@@ -155,8 +171,8 @@ def test_nplayer_trajectory_featurised_by_one_launch(case, n):
 def test_four_player_drop_in_env_and_buffers():
     """OvercookedMadrona("multiplayer_schelling", ...) as the reference constructs it (envs/overcooked2_env.py:29): three partner
     agents, observations (N, 7, 7, 30); the time-major TrajectoryBuffer, per-kitchen episode control and state export / import /
-    re-featurisation work for any player count, and so do tape rollouts, groups and trajectory re-featurisation (as sequences of plain
-    launches); only the built-in 2-player action stream refuses politely."""
+    re-featurisation work for any player count, and so do tape rollouts, groups and trajectory re-featurisation (since round 5
+    one launch each, groups a launch per engine); only the built-in 2-player action stream refuses politely."""
     from diverse_conventions_amd import (EngineGroup, OvercookedEngine, OvercookedMadrona, RandomVectorAgent, TrajectoryBuffer,
                                          get_base_layout_params)
     from diverse_conventions_amd.native import OvercookedNativeError
@@ -207,7 +223,7 @@ def test_four_player_drop_in_env_and_buffers():
     assert np.array_equal(tiles[0], start[0][0]) and np.array_equal(players[0], start[1][0]) and np.all(ts == 195)
     _, _, d = eng.rollout(dacts[:5, :, :, 0].to(torch.int32).contiguous(), 5)
     assert int(d.sum()) == n                                          # every kitchen reached the horizon at the fifth step
-    # what is ONE fused launch for two players is the equivalent sequence of plain launches here -- same calls, same results:
+    # what is ONE fused launch for two players is one launch here as well (tape rollouts, trajectories; a launch per engine for groups):
     # a tape rollout (oc_rollout / oc_rollout_fused) against the oracle ...
     tape = rng.integers(0, 6, size=(7, 4, n)).astype(np.int32)
     dtape = torch.from_numpy(tape).cuda()
