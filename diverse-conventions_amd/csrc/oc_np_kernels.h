@@ -28,8 +28,8 @@ constexpr int kMaxP = 4;
 
 struct NpArgs {
     uint32_t *state;                // [N][recd]
-    const uint32_t *terrain;        // [S]
-    const uint32_t *out_tab2;       // [2S]: low byte of entry 2*o = state tile index of output tile o = x*H + y
+    const uint32_t *tabs;           // the engine's table image (prepare_engine): [out_tab2 2S | terrain S | recipe values 16 | recipe times 16 | ...];
+                                    // low byte of out_tab2[2 * o] = state tile index t of output tile o = x * H + y
     const void *actions;            // [P][N] i32 or i64 (NULL: encode only)
     int act64;
     int8_t *obs;                    // viewer v at obs + v * obs_player_stride; [N][W][H][C]
@@ -38,7 +38,6 @@ struct NpArgs {
     int64_t n;
     int32_t W, H, S, P, C, recd;
     int32_t horizon, placement_rew, soup_rew;
-    int32_t rvalues[16], rtimes[16];
     uint32_t start_pp[kMaxP];
     uint32_t *rec_out;              // the post-step (STEP) / the featurised (!STEP) records also go here ([N][recd], 16-byte aligned: the trajectory's slot); NULL: not recorded
     int32_t K, G;                   // launch geometry: kitchens per group, passes of 64 tiles per flush (NpGeom)
@@ -82,8 +81,10 @@ struct NpGeom { int K, G; };                               // kitchens per group
 // (x + 0.5) / d is at least 0.5 / d away from an integer, the f32 product's error stays below 2^-20 of it
 __device__ __forceinline__ int np_div(int x, float inv) { return static_cast<int>((static_cast<float>(x) + 0.5f) * inv); }
 __host__ __device__ inline int np_lstride(int recd) { return recd | 1; }            // odd: lanes = kitchens hit distinct banks
-// LDS of one wavefront, in dwords: [terrain S][tab S][rvalues 16][rtimes 16][state K * lstride][done K][dump 16][staging P * G * 64 * C bytes]
-__host__ __device__ inline int np_lds_fixed_dwords(int S, int recd, int K) { return (2 * S + 32 + K * np_lstride(recd) + K + 16 + 3) & ~3; }
+// LDS of one wavefront, in dwords: [table image: out_tab2 2S | terrain S | rvalues 16 | rtimes 16, whole 16-byte chunks][tab S][state K * lstride]
+// [done K][dump 16][staging P * G * 64 * C bytes]
+__host__ __device__ inline int np_img_dwords(int S) { return (3 * S + 32 + 3) & ~3; }
+__host__ __device__ inline int np_lds_fixed_dwords(int S, int recd, int K) { return (np_img_dwords(S) + S + K * np_lstride(recd) + K + 16 + 3) & ~3; }
 __host__ __device__ inline size_t np_lds_bytes(int S, int P, int recd, NpGeom g) {
     return static_cast<size_t>(np_lds_fixed_dwords(S, recd, g.K)) * 4 + static_cast<size_t>(P) * g.G * 64 * (5 * P + 10);
 }
@@ -96,17 +97,17 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     // Every kernel argument the wavefront will use, asked for at once: left alone the compiler loads each field next to its first use,
     // one scalar-memory round trip after the other in front of the first memory request (five of them in one build: +0.5 us per launch
     // on every shape -- 5.5 -> 6.1 us at 8192 one-player kitchens; seen in the listing, as for the 2-player kernel in round 3).
-    asm volatile("" : : "s"(a.state), "s"(a.terrain), "s"(a.actions), "s"(a.obs), "s"(a.reward), "s"(a.done), "s"(a.rec_out), "s"(a.n),
+    asm volatile("" : : "s"(a.state), "s"(a.tabs), "s"(a.actions), "s"(a.obs), "s"(a.reward), "s"(a.done), "s"(a.rec_out), "s"(a.n),
                  "s"(a.obs_player_stride), "s"(a.S), "s"(a.W), "s"(a.H), "s"(a.recd), "s"(a.K), "s"(a.G), "s"(a.act64));
     asm volatile("" : : "s"(a.horizon), "s"(a.placement_rew), "s"(a.soup_rew), "s"(a.inv_S), "s"(a.inv_H), "s"(a.inv_W), "s"(a.inv_recq),
                  "s"(a.no_pipeline), "s"(a.items), "s"(a.state_item_stride), "s"(a.obs_item_stride), "s"(a.n_steps), "s"(a.tape_steps));
     const int S = a.S, W = a.W, H = a.H, recd = a.recd, recq = recd >> 2, K = a.K, G = a.G;
     const int lstride = np_lstride(recd);
-    uint32_t *const l_terr = np_lds;                       // [S] terrain code of state tile t
-    uint32_t *const l_tab = np_lds + S;                    // [S] by output tile o = x * H + y: t | terrain << 8
-    int32_t *const l_rval = reinterpret_cast<int32_t *>(np_lds + 2 * S);
+    uint32_t *const l_terr = np_lds + 2 * S;               // [S] terrain code of state tile t (the image's terrain section)
+    int32_t *const l_rval = reinterpret_cast<int32_t *>(np_lds + 3 * S);
     int32_t *const l_rtime = l_rval + 16;
-    uint32_t *const l_state = np_lds + 2 * S + 32;         // [K][lstride]
+    uint32_t *const l_tab = np_lds + np_img_dwords(S);     // [S] by output tile o = x * H + y: t | terrain << 8
+    uint32_t *const l_state = l_tab + S;                   // [K][lstride]
     uint32_t *const l_done = l_state + K * lstride;        // [K]
     uint32_t *const l_dump = l_done + K;                   // 16 dwords nobody reads
     int8_t *const l_stage = reinterpret_cast<int8_t *>(np_lds + np_lds_fixed_dwords(S, recd, K));    // [P][G * 64 * C]
@@ -150,14 +151,29 @@ __global__ __launch_bounds__(64) void np_group_kernel(const NpArgs a) {
     };
 #pragma unroll
     for (int i = 0; i < P; ++i) pa[i] = A_STAY;
-    if (aligned && static_cast<int64_t>(blockIdx.x) < n_groups) prefetch(blockIdx.x);     // the first group's loads: in flight during the table setup
-    // ---- tables, once per wavefront
-    for (int t = lane; t < S; t += 64) l_terr[t] = a.terrain[t];
-    for (int o = lane; o < S; o += 64) {
-        const int x = np_div(o, a.inv_H), y = o - x * H, t = y * W + x;
-        l_tab[o] = static_cast<uint32_t>(t) | (a.terrain[t] << 8);
+    // ---- tables, once per wavefront: the head of the engine's table image as ONE flat 16-byte copy -- its loads go out first (L2
+    //      hits), the first group's records and actions (HBM) behind them, and land through an empty asm (as three loops over
+    //      terrain / tile map / recipe tables the compiler made three or four serial round trips of it, the first behind the records:
+    //      the 2-player kernel's lesson of round 3)
+    {
+        const u32x4 *img = reinterpret_cast<const u32x4 *>(a.tabs);
+        const int nq4 = np_img_dwords(S) >> 2;
+        u32x4 tq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tq[q] = img[min(lane + q * 64, nq4 - 1)];
+        if (aligned && static_cast<int64_t>(blockIdx.x) < n_groups) prefetch(blockIdx.x);     // the first group's loads: in flight during the table setup
+#pragma unroll
+        for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(tq[q]));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (lane + q * 64 < nq4) reinterpret_cast<u32x4 *>(np_lds)[lane + q * 64] = tq[q];
+        for (int c = lane + 128; c < nq4; c += 64) reinterpret_cast<u32x4 *>(np_lds)[c] = img[c];       // grids of more than 160 tiles
     }
-    if (lane < 16) { l_rval[lane] = a.rvalues[lane]; l_rtime[lane] = a.rtimes[lane]; }
+    wave_sync();
+    for (int o = lane; o < S; o += 64) {
+        const uint32_t t = np_lds[2 * o] & 0xff;
+        l_tab[o] = t | (l_terr[t] << 8);
+    }
     land_prefetch();
     wave_sync();
 
