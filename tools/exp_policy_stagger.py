@@ -5,7 +5,8 @@ delaying waves 4-7 puts one wave's tail beside its partner's loop (MI355X_MICROA
     OC_DIAGNOSTICS=1 OC_POLICY_DESYNC=<units of 64 cycles> python tools/exp_policy_stagger.py      (one process per value: read once)
 Negative values ablate instead (timing only, outputs missing): -1 every block ends behind the head (no epilogue), -2 behind fc2, -3 behind
 the position loop.  MI355X, 131 070 / 245 760 rows: 37.7 / 56.3 us; stagger 50..400: 37.3-40.1 / 56.2-58.4; ablations 35.8 / 33.2 / 31.4 and
-53.8 / 50.9 / 46.6."""
+53.8 / 50.9 / 46.6.  (A static `s_setprio 1` for waves 4-7, or for waves 0-3 -- the same guide's item 4 -- was tried the same way on
+another box: 39.9 -> 42.6 / 39.9 us and 63.9 -> 63.5 / 64.0: nothing; not kept.)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
