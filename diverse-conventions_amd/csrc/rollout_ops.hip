@@ -312,26 +312,44 @@ __global__ __launch_bounds__(256) void oc_gather_rows_kernel(const GatherArgs a)
         const int lo = static_cast<int>(r), hi = static_cast<int>(r >> 32);
         const int total = rows * a.units;
         uint8_t *out = a.dst + base * static_cast<long long>(a.units) * DST_UNIT;
-        for (int c0 = 0; c0 < total; c0 += 64) {                             // wave-uniform trip count: the cross-lane
-            const int c = c0 + lane;                                         // reads below need every lane alive
-            // row of unit c within the batch: c < 64 * 1280, so the float quotient is exact (error < 0.5 / units)
-            const int row = min(static_cast<int>((static_cast<float>(c) + 0.5f) * a.inv_units), 63);
-            const int k = c - row * a.units;
-            const long long sr = (static_cast<long long>(__shfl(hi, row)) << 32) | static_cast<uint32_t>(__shfl(lo, row));
-            if (c >= total) continue;
-            const uint8_t *in = a.src + sr * a.row_bytes + static_cast<long long>(k) * SRC_UNIT;
-            if (MODE == GATHER_COPY16) {
-                *reinterpret_cast<u32x4 *>(out + static_cast<long long>(c) * 16) = *reinterpret_cast<const u32x4 *>(in);
-            } else if (MODE == GATHER_COPY4) {
-                *reinterpret_cast<uint32_t *>(out + static_cast<long long>(c) * 4) = *reinterpret_cast<const uint32_t *>(in);
-            } else {
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(in);
-                f32x4 f;
-                f.x = static_cast<float>(static_cast<int8_t>(w));
-                f.y = static_cast<float>(static_cast<int8_t>(w >> 8));
-                f.z = static_cast<float>(static_cast<int8_t>(w >> 16));
-                f.w = static_cast<float>(static_cast<int8_t>(w >> 24));
-                *reinterpret_cast<f32x4 *>(out + static_cast<long long>(c) * 16) = f;
+        // Four units per lane in flight (round 5): all four loads -- unconditional, the unit index clamped into the batch -- are issued
+        // before the first store.  As one load / one store per iteration (rounds 1-4) a wavefront had a single kilobyte in flight and
+        // waited out a memory round trip per unit: 0.52 of the HBM roofline on 400-byte rows (profiles/r01_bench_minibatch.log).
+        constexpr int kIlp = 4;
+        for (int c0 = 0; c0 < total; c0 += 64 * kIlp) {                      // wave-uniform trip count: the cross-lane reads
+            u32x4 v16[kIlp];                                                 // below need every lane alive
+            uint32_t v4[kIlp];
+            int cs[kIlp];
+#pragma unroll
+            for (int j = 0; j < kIlp; ++j) {
+                const int c = c0 + j * 64 + lane;
+                cs[j] = c;
+                const int cc = min(c, total - 1);
+                // row of unit cc within the batch: cc < 64 * 1280, so the float quotient is exact (error < 0.5 / units)
+                const int row = min(static_cast<int>((static_cast<float>(cc) + 0.5f) * a.inv_units), 63);
+                const int k = cc - row * a.units;
+                const long long sr = (static_cast<long long>(__shfl(hi, row)) << 32) | static_cast<uint32_t>(__shfl(lo, row));
+                const uint8_t *in = a.src + sr * a.row_bytes + static_cast<long long>(k) * SRC_UNIT;
+                if (MODE == GATHER_COPY16) v16[j] = *reinterpret_cast<const u32x4 *>(in);
+                else v4[j] = *reinterpret_cast<const uint32_t *>(in);
+            }
+#pragma unroll
+            for (int j = 0; j < kIlp; ++j) {
+                const int c = cs[j];
+                if (c >= total) continue;
+                if (MODE == GATHER_COPY16) {
+                    *reinterpret_cast<u32x4 *>(out + static_cast<long long>(c) * 16) = v16[j];
+                } else if (MODE == GATHER_COPY4) {
+                    *reinterpret_cast<uint32_t *>(out + static_cast<long long>(c) * 4) = v4[j];
+                } else {
+                    const uint32_t w = v4[j];
+                    f32x4 f;
+                    f.x = static_cast<float>(static_cast<int8_t>(w));
+                    f.y = static_cast<float>(static_cast<int8_t>(w >> 8));
+                    f.z = static_cast<float>(static_cast<int8_t>(w >> 16));
+                    f.w = static_cast<float>(static_cast<int8_t>(w >> 24));
+                    *reinterpret_cast<f32x4 *>(out + static_cast<long long>(c) * 16) = f;
+                }
             }
         }
     }
