@@ -79,8 +79,8 @@ class PackedNetworks:
     reference's f32 forward does not, and a layer whose weights span more than ~2^14 in magnitude loses the low bits of its
     smallest weights (below 2^-24 of the layer's largest product).  Networks of the reference's training stay orders of magnitude
     inside both (activations of O(1-100)); `activation_range(i, obs)` evaluates network i in f32 with PyTorch on the rows given and
-    reports the largest activation per layer, `pack(..., check_finite=True)` (the default) refuses NaN / Inf weights -- the
-    device-side scale search skips non-finite weights, so they would otherwise pack into garbage silently."""
+    reports the largest activation per layer; `from_state_dicts` and `check_finite()` (or `pack(..., check_finite=True)`) refuse NaN / Inf
+    weights -- the device-side scale search skips non-finite weights, so they would otherwise pack into garbage silently."""
 
     def __init__(self, obs_shape, n_nets, device, digits=DEFAULT_DIGITS):
         self.W, self.H = int(obs_shape[0]), int(obs_shape[1])
@@ -97,12 +97,13 @@ class PackedNetworks:
         self.n_out = [0] * self.n_nets
         self._keep = {}
 
-    def pack(self, index, state_dict, head=ACTOR_HEAD, check_finite=True):
+    def pack(self, index, state_dict, head=ACTOR_HEAD, check_finite=False):
         """state_dict: an R_Actor / R_Critic of the reference's default configuration -- CNNBase with ReLU (`--use_ReLU`
         left at its default; the activation has no parameters, so a Tanh network cannot be told apart here) and no
         recurrent layer (`--use_recurrent_policy` off, as in every training script of the reference).
-        check_finite: raise ValueError on NaN / Inf parameters (one device reduction and a host read per call -- pack() runs once
-        per optimiser step, not per env step; pass False inside a stream capture)."""
+        check_finite: raise ValueError on NaN / Inf parameters of THIS network before packing (reductions and a host read: ~0.2 ms
+        against the 40-60 us of the pack itself, so off by default for re-packs behind an optimiser step; `from_state_dicts` checks
+        everything it packed with one read, `check_finite()` does the same for the networks packed since)."""
         if any(k.startswith("rnn.") for k in state_dict):
             raise NotImplementedError("recurrent policies (rnn.* parameters) are not evaluated by the fused kernel; "
                                       "the reference's training scripts do not enable them")
@@ -112,9 +113,8 @@ class PackedNetworks:
         P = (self.W - 2) * (self.H - 2)
         if tuple(src[0].shape) != (hidden // 2, 20, 3, 3) or tuple(src[2].shape) != (hidden, hidden // 2 * P):
             raise ValueError(f"network {index} does not have the reference CNNBase shape for a {self.W}x{self.H} grid")
-        if check_finite and not bool(torch.stack([x.isfinite().all() for x in src]).all()):
-            bad = [k for k, x in zip(_KEYS + (head + ".weight", head + ".bias"), src) if not bool(x.isfinite().all())]
-            raise ValueError(f"network {index}: non-finite values in {', '.join(bad)}")
+        if check_finite:
+            self._raise_if_nonfinite({index: (src, head)})
         self._keep[index] = src                      # the pack kernel reads them asynchronously
         self._heads = getattr(self, "_heads", {})
         self._heads[index] = head
@@ -122,6 +122,29 @@ class PackedNetworks:
                                                  *[_ptr(x) for x in src], _ptr(self.image[index]), _stream(self.device)))
         self.n_out[index] = n_out
         return index
+
+    @staticmethod
+    def _raise_if_nonfinite(nets):
+        """nets: {index: (tensors, head)} -> ValueError naming the first network and parameters that hold NaN / Inf.  One fused norm
+        over all tensors and ONE host read when everything is finite."""
+        flat = [x for src, _ in nets.values() for x in src]
+        try:
+            norms = torch.stack(torch._foreach_norm(flat))
+        except (AttributeError, RuntimeError):
+            norms = torch.stack([x.abs().max() if x.numel() else x.new_zeros(()) for x in flat])
+        if bool(norms.isfinite().all()):
+            return
+        for index, (src, head) in nets.items():
+            bad = [k for k, x in zip(_KEYS + (head + ".weight", head + ".bias"), src) if not bool(x.isfinite().all())]
+            if bad:
+                raise ValueError(f"network {index}: non-finite values in {', '.join(bad)}")
+
+    def check_finite(self, indices=None):
+        """Raise ValueError if any parameter handed to `pack` (for `indices`, default: every packed network) holds NaN / Inf: one
+        device reduction and one host read for all of them.  The device-side scale search skips non-finite weights, so a network
+        that has them packs into garbage silently -- call this after re-packing networks from an optimiser you do not trust."""
+        idx = list(self._keep) if indices is None else list(indices)
+        self._raise_if_nonfinite({i: (self._keep[i], self._heads[i]) for i in idx})
 
     def activation_range(self, index, obs):
         """Largest hidden activation of network `index` on the rows `obs` (int8 / float [n, W, H, 20], any device), evaluated in f32
@@ -147,6 +170,7 @@ class PackedNetworks:
             nets.pack(i, sd, ACTOR_HEAD)
         for i, sd in enumerate(critics):
             nets.pack(len(actors) + i, sd, CRITIC_HEAD)
+        nets.check_finite()                          # (one read for all of them)
         return nets
 
 

@@ -489,7 +489,13 @@ def test_activation_range_audit_and_saturation():
     bad["base.cnn.cnn.3.weight"] = base["base.cnn.cnn.3.weight"].copy()
     bad["base.cnn.cnn.3.weight"][3, 7] = np.inf
     with pytest.raises(ValueError, match="non-finite"):
-        PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[bad])
+        PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[base, bad])          # (one check for everything packed)
+    with pytest.raises(ValueError, match="network 0: non-finite values in base.cnn.cnn.3.weight"):
+        PackedNetworks((5, 4, 20), 1, "cuda").pack(0, bad, check_finite=True)
+    repacked = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[base])
+    repacked.pack(0, bad)                                               # a re-pack does not check by itself ...
+    with pytest.raises(ValueError, match="non-finite"):
+        repacked.check_finite()                                         # ... the batched check does
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[base])
     r0 = nets.activation_range(0, obs)
     assert not r0["saturates"] and r0["limit"] == ACTIVATION_LIMIT == 4094.0
