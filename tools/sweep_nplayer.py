@@ -11,10 +11,10 @@ for P in players:
     layout, maxp = ("simple_single", None) if P == 1 else ("multiplayer_schelling", P)
     params = get_base_layout_params(layout, 200, max_num_players=maxp)
     S = params["width"] * params["height"]
-    for n in (65536, 8192):
+    for n in [int(x) for x in os.environ.get("OC_SWEEP_N", "65536,8192").split(",")]:
         acts = torch.randint(0, 6, (64, P, n), device="cuda", dtype=torch.int32)
         best = None
-        for sm in (0, 2, 4):
+        for sm in [int(x) for x in os.environ.get("OC_SWEEP_SM", "0,2,4").split(",")]:
             os.environ["OC_NP_SM"] = str(sm)
             for K, G, w in ((0, 0, 0), (16, 2, 8), (16, 1, 8), (16, 3, 8), (16, 4, 6), (8, 2, 8), (8, 2, 12), (8, 4, 8), (16, 2, 6), (16, 2, 4), (4, 2, 16), (12, 2, 8), (32, 2, 8), (32, 3, 8), (32, 4, 8), (40, 3, 8), (20, 2, 8)):
                 if K * P > 64:
