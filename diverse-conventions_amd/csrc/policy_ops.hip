@@ -1173,12 +1173,20 @@ int64_t oc_policy_plan_tiles_multi(const int64_t *seg_row0, const int64_t *seg_r
     return n;
 }
 
+// (defined below; the CU-budget / per-engine-stream forms are reachable from outside only through the diagnostics library's oc_exp_* entry points)
+static int policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                              const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                              float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                              const int32_t *d_row_select, int32_t cu_budget, void *stream);
+static int group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
+                                        int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
+
 int oc_policy_forward(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                       const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
                       float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                       const int32_t *d_row_select, void *stream) {
-    return oc_exp_policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode,
-                                     seed, counter, d_counter, d_row_select, 0, stream);
+    return policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode,
+                              seed, counter, d_counter, d_row_select, 0, stream);
 }
 
 }  // extern "C"
@@ -1410,7 +1418,9 @@ static int policy_forward_impl(const oc_policy_shape *shape, const void *d_packe
     return launch_policy(a, shape->digits, false, cu_budget, static_cast<hipStream_t>(stream));
 }
 
-int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+// (cu_budget > 0: the launch is sized for a CU-masked stream's share -- the CU-partition experiment of round 2, reachable through
+// oc_exp_policy_forward_cus in the diagnostics library only; the product's entry points pass 0 = the whole device)
+static int policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
                               const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
                               float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
                               const int32_t *d_row_select, int32_t cu_budget, void *stream) {
@@ -1559,6 +1569,7 @@ int oc_policy_rollout_mixed(oc_engine *e, const oc_policy_shape *shape, const vo
     return OC_OK;
 }
 
+#ifdef OC_DIAGNOSTICS
 int oc_exp_cu_partition_create(int device_id, const float *shares, int32_t n, void **out_streams, int32_t *out_cus) {
     if (!shares || !out_streams || n < 1 || n > 64) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_exp_cu_partition_create: 1..64 streams");
     const OcDeviceScope on_device(device_id);
@@ -1625,12 +1636,25 @@ int oc_exp_cu_partition_destroy(void *const *streams, int32_t n) {
     return OC_OK;
 }
 
+int oc_exp_policy_forward_cus(const oc_policy_shape *shape, const void *d_packed, int32_t n_nets, const int8_t *d_obs, int64_t n_rows,
+                              const int32_t *d_tiles, int32_t n_tiles, float *d_raw, int32_t *d_actions, float *d_action_logp,
+                              float *d_logp, int sample_mode, uint32_t seed, uint32_t counter, const uint32_t *d_counter,
+                              const int32_t *d_row_select, int32_t cu_budget, void *stream) {
+    return policy_forward_cus(shape, d_packed, n_nets, d_obs, n_rows, d_tiles, n_tiles, d_raw, d_actions, d_action_logp, d_logp, sample_mode, seed, counter,
+                              d_counter, d_row_select, cu_budget, stream);
+}
+int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
+                                        int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
+    return group_policy_rollout_streams(g, slots, policy_streams, cu_budgets, T, in_place, sample_mode, seed, counter0, stream);
+}
+#endif  // OC_DIAGNOSTICS: the oc_exp_* entry points
+
 int oc_group_policy_rollout(oc_group *g, const oc_group_policy_slot *slots, int64_t T, int in_place, int sample_mode, uint32_t seed,
                             uint32_t counter0, void *stream) {
-    return oc_exp_group_policy_rollout_streams(g, slots, nullptr, nullptr, T, in_place, sample_mode, seed, counter0, stream);
+    return group_policy_rollout_streams(g, slots, nullptr, nullptr, T, in_place, sample_mode, seed, counter0, stream);
 }
 
-int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
+static int group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
                                         int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream) {
     const int n = oc_group_size(g);
     if (n < 1 || !slots || T < 0) return oc_internal_fail(OC_ERR_INVALID_ARG, "oc_group_policy_rollout: NULL group / slots or negative T");
@@ -1661,7 +1685,7 @@ int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot 
     auto policy = [&](int i, int64_t t, hipStream_t st, int budget) {
         const oc_group_policy_slot &s = slots[i];
         const int64_t k = in_place ? 0 : t;
-        return oc_exp_policy_forward_cus(s.shape, s.d_packed, s.n_nets, s.d_obs + k * slot_bytes[i], rows[i], s.d_tiles, s.n_tiles,
+        return policy_forward_cus(s.shape, s.d_packed, s.n_nets, s.d_obs + k * slot_bytes[i], rows[i], s.d_tiles, s.n_tiles,
                                      s.d_values ? s.d_values + k * rows[i] : nullptr, s.d_actions + k * rows[i],
                                      s.d_action_logp ? s.d_action_logp + k * rows[i] : nullptr, nullptr, sample_mode,
                                      seed + static_cast<uint32_t>(i) * 0x9E3779B9u, counter0 + static_cast<uint32_t>(t), nullptr, nullptr, budget, st);

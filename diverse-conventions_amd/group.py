@@ -138,7 +138,7 @@ class GroupPairedRollout:
     def __init__(self, group: EngineGroup, nets, threads, n_conventions: int, critic_nets=None, deterministic: bool = False, seed: int = 0,
                  partition="auto"):
         from .fused_policy import TILE_ACT, _shape
-        from .policy import segment_policy_indices
+        from .sharding import segment_policy_indices
         from .sharding import pairing_segments
         self.group, self.nets, self.deterministic, self.seed = group, list(nets), deterministic, int(seed)
         n_eng = len(group)

@@ -60,7 +60,8 @@ SYMBOLS_OPS = [
     "oc_partition_rows", "oc_policy_forward_gather", "oc_policy_rollout_mixed",
 ]
 SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
-# include/overcooked_experiments.h (measured and not adopted; tools/ only) and include/overcooked_debug.h (diagnostics)
+# include/overcooked_experiments.h (measured and not adopted; tools/ only: exported by the diagnostics build only since round 6)
+# and include/overcooked_debug.h (diagnostics)
 SYMBOLS_EXPERIMENTS = ["oc_exp_cu_partition_create", "oc_exp_cu_partition_destroy", "oc_exp_policy_forward_cus", "oc_exp_set_cu_budget",
                        "oc_exp_group_policy_rollout_streams"]
 SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group"]
@@ -202,7 +203,6 @@ def lib():
     L.oc_device_id.argtypes = [vp]
     L.oc_set_tuning.argtypes = [vp, i32, i32, i32]
     L.oc_prepare_kernels.argtypes = [vp]
-    L.oc_exp_set_cu_budget.argtypes = [vp, ctypes.c_int32]
     fp = ctypes.c_float
     L.oc_gae_returns.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.c_double, i32, fp, fp, i32, vp]
     L.oc_advantage_workspace_bytes.argtypes = []
@@ -225,13 +225,14 @@ def lib():
     L.oc_policy_forward_gather.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, i64, vp, vp, vp, vp, i32, u32, u32, vp, vp]
     L.oc_policy_rollout_mixed.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, vp, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp, vp, vp]
     L.oc_policy_rollout.argtypes = [vp, ps, vp, ctypes.c_int32, vp, ctypes.c_int32, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, u32, u32, vp, vp]
-    L.oc_exp_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
-    L.oc_exp_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
-    L.oc_exp_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
     L.oc_group_policy_rollout.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), i64, i32, i32, u32, u32, vp]
-    L.oc_exp_group_policy_rollout_streams.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
-                                                      u32, u32, vp]
     if DIAGNOSTICS:
+        L.oc_exp_set_cu_budget.argtypes = [vp, ctypes.c_int32]
+        L.oc_exp_policy_forward_cus.argtypes = [ps, vp, ctypes.c_int32, vp, i64, vp, ctypes.c_int32, vp, vp, vp, vp, i32, u32, u32, vp, vp, ctypes.c_int32, vp]
+        L.oc_exp_cu_partition_create.argtypes = [i32, ctypes.POINTER(ctypes.c_float), ctypes.c_int32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
+        L.oc_exp_cu_partition_destroy.argtypes = [ctypes.POINTER(vp), ctypes.c_int32]
+        L.oc_exp_group_policy_rollout_streams.argtypes = [vp, ctypes.POINTER(OcGroupPolicySlot), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), i64, i32, i32,
+                                                          u32, u32, vp]
         L.oc_debug_trace.argtypes = [vp, i32, vp, i64]
         L.oc_policy_debug_trace.argtypes = [i32, vp, i64]
         L.oc_debug_fold_launches.argtypes = []
@@ -263,7 +264,7 @@ def lib():
     L.oc_group_build_info.restype = ctypes.c_char_p
     L.oc_debug_jit_compile_group.argtypes = [ctypes.POINTER(OcLayoutParams), ctypes.POINTER(i64), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, i64]
-    for name in SYMBOLS + SYMBOLS_EXPERIMENTS + SYMBOLS_DEBUG + (SYMBOLS_DIAG if DIAGNOSTICS else []):
+    for name in SYMBOLS + SYMBOLS_DEBUG + (SYMBOLS_EXPERIMENTS + SYMBOLS_DIAG if DIAGNOSTICS else []):
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:          # default restype: int status
             fn.restype = ctypes.c_int

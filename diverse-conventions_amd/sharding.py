@@ -189,3 +189,8 @@ def best_partner(scores: torch.Tensor, n_conventions: int, xp_weight: float = 1.
     k = n_conventions
     both = xp_weight * (scores[1:1 + k] + scores[1 + k:1 + 2 * k])
     return int(both.argmax())
+
+
+def segment_policy_indices(segments, side: str) -> list:
+    """Policy index per pairing segment for 'ego' or 'partner' (see sharding.pairing_segments)."""
+    return [s.ego_policy if side == "ego" else s.partner_policy for s in segments]

@@ -1,7 +1,8 @@
 /*
- * overcooked_experiments.h -- entry points of experiments that were built, measured and NOT adopted.  They stay in the library
- * so that tools/ can re-run the measurement (tools/exp_cu_mask.py, exp_cu_partition_parts.py, exp_group_streams.py); nothing in
- * the package or the tests calls them, and they are not part of the drop-in boundary: signatures may change without an ABI bump.
+ * overcooked_experiments.h -- entry points of experiments that were built, measured and NOT adopted.  They exist in the
+ * DIAGNOSTICS build of the library only (-DOC_DIAGNOSTICS -> csrc/liboc_hip_diag.so, what tools/ load: tools/exp_cu_mask.py,
+ * exp_cu_partition_parts.py, exp_group_streams.py); the shipped liboc_hip.so exports none of them (round 6), nothing in the package
+ * calls them, and they are not part of the drop-in boundary: signatures may change without an ABI bump.
  *
  * CU-masked streams: k mask bits give k CUs and proportional throughput (tools/probes/cu_mask.hip), and two isolated policy
  * launches of 8184 asymmetric_advantages kitchens take 49.6 us together on two half-device streams against 91 us one after the
@@ -18,6 +19,7 @@
 extern "C" {
 #endif
 
+#ifdef OC_DIAGNOSTICS
 /* n HIP streams restricted to disjoint sets of the device's CUs, stream i getting about shares[i] / sum(shares) of them (at
  * least one; every set spread over the whole CU index range).  out_streams: n hipStream_t (as void*), out_cus (optional): CUs
  * given to each.  Destroy with oc_exp_cu_partition_destroy. */
@@ -38,6 +40,7 @@ int oc_exp_set_cu_budget(oc_engine *e, int32_t cus);
  * results as oc_group_policy_rollout. */
 int oc_exp_group_policy_rollout_streams(oc_group *g, const oc_group_policy_slot *slots, void *const *policy_streams, const int32_t *cu_budgets,
                                         int64_t T, int in_place, int sample_mode, uint32_t seed, uint32_t counter0, void *stream);
+#endif
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tools") not in sys.path:          # tools/torch_policies.py: the plain-PyTorch fp32 reference of the fused policy kernel
+    sys.path.insert(1, os.path.join(ROOT, "tools"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

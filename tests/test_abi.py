@@ -27,10 +27,11 @@ def test_library_exports_every_declared_symbol():
     L = native.lib()
     assert sorted(native.SYMBOLS_ENV) == header_functions("overcooked_hip.h")
     assert sorted(native.SYMBOLS_OPS) == header_functions("overcooked_ops.h")
-    assert sorted(native.SYMBOLS_EXPERIMENTS) == header_functions("overcooked_experiments.h")
+    assert sorted(native.SYMBOLS_EXPERIMENTS) == header_functions("overcooked_experiments.h", diagnostics=True)
+    assert header_functions("overcooked_experiments.h") == []          # nothing of it outside the diagnostics build (round 6)
     assert sorted(native.SYMBOLS_DEBUG) == header_functions("overcooked_debug.h")
     assert sorted(native.SYMBOLS_DIAG) == header_functions("overcooked_debug.h", diagnostics=True)
-    declared = native.SYMBOLS + native.SYMBOLS_EXPERIMENTS + native.SYMBOLS_DEBUG + (native.SYMBOLS_DIAG if native.DIAGNOSTICS else [])
+    declared = native.SYMBOLS + native.SYMBOLS_DEBUG + (native.SYMBOLS_EXPERIMENTS + native.SYMBOLS_DIAG if native.DIAGNOSTICS else [])
     for name in declared:
         assert getattr(L, name) is not None, name
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
@@ -55,7 +56,8 @@ def test_product_library_carries_no_diagnostics():
     for kept in (b"OC_NO_JIT", b"OC_JIT_CACHE", b"OC_DWORD_STORES", b"OC_POLICY_COOP"):      # the documented switches of the product
         assert kept in blob, kept
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
-    assert not [s for s in native.SYMBOLS_DIAG if s in nm]
+    assert not [s for s in native.SYMBOLS_DIAG + native.SYMBOLS_EXPERIMENTS if s in nm]
+    assert b"oc_exp_" not in blob                                      # the experiments' entry points: not even as error-message strings
 
 
 def test_layout_struct_matches_header():

@@ -56,7 +56,8 @@ def _check_policies(ro, traj, logp, values, actors_sd, critics_sd, critic_of, T,
     """Recorded log-probs are those of the recorded actions under the segment's actor, recorded values those of its critic
     (PyTorch f32 evaluation of the reference architecture; the fused kernel agrees to ~1e-6, the tolerance leaves room for
     the different summation order of 21-position grids)."""
-    from diverse_conventions_amd.policy import StackedActors, StackedCritics, segment_policy_indices
+    from torch_policies import StackedActors, StackedCritics
+    from diverse_conventions_amd.sharding import segment_policy_indices
     W, H, _ = shape
     G, threads, n = len(ro.segments), ro.threads, traj.obs.shape[2]
     sa, sc = StackedActors(actors_sd, shape, "cuda"), StackedCritics(critics_sd, shape, "cuda")
@@ -76,7 +77,7 @@ def _check_policies(ro, traj, logp, values, actors_sd, critics_sd, critic_of, T,
 def test_config4_one_gpu_share(layout_params):
     from diverse_conventions_amd import (FusedPairedRollout, MixedPlayRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer,
                                          TrajectoryExchange)
-    from diverse_conventions_amd.policy import StackedActors, StackedCritics
+    from torch_policies import StackedActors, StackedCritics
     params = layout_params["unident_s"]                       # asymmetric_advantages
     W, H, shape = 9, 5, (9, 5, 20)
     k, G = 15, 31
@@ -313,7 +314,8 @@ def test_policy_rollout_into_fresh_slots_at_the_large_batch_geometry(layout_para
             assert np.array_equal(traj.reward[t][:, sl].cpu().numpy(), orew) and np.array_equal(traj.done[t][sl].cpu().numpy(), odone), (f, t)
     assert int(traj.done.sum()) > 0                                   # the horizon was crossed inside the collection
     # the log-probabilities recorded for the sampled kitchens' actions: the segment's actor on the recorded observations
-    from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+    from torch_policies import StackedActors
+    from diverse_conventions_amd.sharding import segment_policy_indices
     sa = StackedActors(actors, (5, 4, 20), "cuda")
     for p, side in enumerate(("ego", "partner")):
         pol = segment_policy_indices(ro.segments, side)

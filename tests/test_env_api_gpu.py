@@ -90,7 +90,7 @@ def test_fused_partner_agent_in_the_reference_loop(layout_params):
     import os
     from conftest import GOLDEN
     from diverse_conventions_amd import FusedVectorAgent, PackedNetworks, generate_env
-    from diverse_conventions_amd.policy import StackedActors, StackedCritics
+    from torch_policies import StackedActors, StackedCritics
     z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
     pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}
     actors, critics = [pick(f"a{i}.") for i in range(3)], [pick("c0.")]

@@ -74,7 +74,7 @@ def test_mixed_play_rollout_on_the_engine(layout_params):
     buffer as one gather: checked against per-network PyTorch evaluation, the oracle env and the oracle placement."""
     from diverse_conventions_amd import OvercookedEngine, PackedNetworks
     from diverse_conventions_amd.mixed_play import MixedPlayRollout
-    from diverse_conventions_amd.policy import StackedActors, StackedCritics
+    from torch_policies import StackedActors, StackedCritics
     from oracle import oracle
     z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
     pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}

@@ -149,8 +149,8 @@ def test_paired_rollout_eager_and_graph(layout_params):
     import os
     from conftest import GOLDEN
     from diverse_conventions_amd import OvercookedEngine
-    from diverse_conventions_amd.policy import StackedActors
-    from diverse_conventions_amd.rollout import PairedRollout
+    from torch_policies import StackedActors
+    from torch_policies import PairedRollout
     z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
     sds = [{k[len(f"a{i}."):]: z[k] for k in z.files if k.startswith(f"a{i}.") and "logits" not in k and "det_" not in k}
            for i in range(3)]
@@ -196,7 +196,7 @@ def test_fused_paired_rollout_eager_graph_and_reference_policies(layout_params):
     rollout, its HIP-graph replay, the batched-GEMM PyTorch path and an oracle env driven by the same actions
     must agree exactly; critic values against the reference-architecture PyTorch evaluation within 2e-6."""
     from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks
-    from diverse_conventions_amd.policy import StackedActors, StackedCritics
+    from torch_policies import StackedActors, StackedCritics
     actors_sd, critics_sd = _golden_nets()
     params = layout_params["simple"]
     threads, k, T = 64, 2, 40
@@ -237,7 +237,7 @@ def test_fused_rollout_collects_a_trajectory_in_place(layout_params):
     t+1 -- the recorded actions replayed through the oracle reproduce every recorded observation/reward/done, the
     recorded log-probs are those of the recorded actions, and sampled graph replays differ from step to step."""
     from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer
-    from diverse_conventions_amd.policy import StackedActors
+    from torch_policies import StackedActors
     actors_sd, critics_sd = _golden_nets()
     params = layout_params["simple"]
     threads, k, T = 96, 1, 30
@@ -277,7 +277,8 @@ def test_fused_rollout_on_every_lds_plan(layout, layout_params):
     4 with them in LDS; 4 or 2 with them in registers; 1 for 14x9): each one in the integrated rollout, sampled actions
     re-evaluated by the PyTorch path on the recorded observations, env against the oracle."""
     from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer
-    from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+    from torch_policies import StackedActors
+    from diverse_conventions_amd.sharding import segment_policy_indices
     from diverse_conventions_amd import get_base_layout_params
     params = layout_params[layout] if layout in layout_params else get_base_layout_params(layout, 200)
     W, H = params["width"], params["height"]

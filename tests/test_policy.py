@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from diverse_conventions_amd.policy import StackedActors, StackedCritics, segment_policy_indices
+from torch_policies import StackedActors, StackedCritics
+from diverse_conventions_amd.sharding import segment_policy_indices
 from diverse_conventions_amd.sharding import pairing_segments
 
 TOL = 2e-5

@@ -4,11 +4,13 @@ per pairing segment, 8 conventions (15 segments), actors + critics for both side
 batched-GEMM PyTorch path (StackedActors + StackedCritics) it replaces.  Random weights of the reference shape."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
 from diverse_conventions_amd.fused_policy import ACTOR_HEAD, CRITIC_HEAD, TILE_ACT, PackedNetworks, PolicyPlan
-from diverse_conventions_amd.policy import StackedActors, StackedCritics, segment_policy_indices
+from torch_policies import StackedActors, StackedCritics
+from diverse_conventions_amd.sharding import segment_policy_indices
 from diverse_conventions_amd.sharding import pairing_segments
 
 

@@ -4,10 +4,12 @@ per step: the batched-GEMM PyTorch path (StackedActors) and the fused MFMA kerne
 and actors + critics).  Random-weight networks of the reference architecture (hidden 64)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
-from diverse_conventions_amd.policy import StackedActors
-from diverse_conventions_amd.rollout import FusedPairedRollout, PairedRollout
+from torch_policies import StackedActors
+from diverse_conventions_amd.rollout import FusedPairedRollout
+from torch_policies import PairedRollout
 from diverse_conventions_amd.fused_policy import PackedNetworks
 
 

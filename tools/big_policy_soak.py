@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from bench_paired_rollout import random_actor
 from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, PackedNetworks, TrajectoryBuffer, get_base_layout_params
-from diverse_conventions_amd.policy import StackedActors, segment_policy_indices
+from torch_policies import StackedActors
+from diverse_conventions_amd.sharding import segment_policy_indices
 from oracle import oracle
 
 threads, k, T, rounds = 4096, 7, 100, 10

@@ -1,17 +1,27 @@
-"""Segment-batched policy inference, PyTorch-ROCm as the north star prescribes for the
-small policy networks.
+"""The PyTorch-ROCm batched-GEMM evaluation of the reference's policy networks and the rollout step built on it: the COMPARISON
+BASELINE of SURVEY.md 8(f2), not a product path (round 6: moved out of the package -- the product evaluates policies with the fused
+MFMA kernel, csrc/policy_ops.hip, 48 us per step where this path takes 684).  tests/ use it as the plain-PyTorch fp32 reference the
+fused kernel is compared with; tools/bench_fused_policy.py and bench_paired_rollout.py time it beside the kernel.
 
-The reference evaluates every convention's actor separately and sequentially on its env segment --
-2(2k+1) tiny CNN forwards of several kernel launches each per env step (train/XD/xd_player.py:190-207,
-train/partner_agents.py:97-111).  `StackedActors` keeps K actors of the reference architecture
-(R_Actor = CNNBase + Categorical head: train/MAPPO/r_actor_critic.py:11-76, utils/cnn.py:12-60,
-utils/act.py, utils/distributions.py:60-80) with their weights stacked on a leading axis and evaluates all
-segments with four batched GEMMs, reading the engine's int8 observations directly (the 3x3 convolution is
-expanded once into a dense matrix over the flattened observation row, so there is no im2col pass).
+The reference evaluates every convention's actor separately and sequentially on its env segment -- 2(2k+1) tiny CNN forwards of
+several kernel launches each per env step (train/XD/xd_player.py:190-207, train/partner_agents.py:97-111).  `StackedActors` keeps K
+actors of the reference architecture (R_Actor = CNNBase + Categorical head: train/MAPPO/r_actor_critic.py:11-76, utils/cnn.py:12-60,
+utils/act.py, utils/distributions.py:60-80) with their weights stacked on a leading axis and evaluates all segments with four batched
+GEMMs, reading the engine's int8 observations directly (the 3x3 convolution is expanded once into a dense matrix over the flattened
+observation row, so there is no im2col pass).
 """
-from typing import List, Sequence
+import os
+import sys
+from typing import Sequence
 
 import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from diverse_conventions_amd.engine import OvercookedEngine                       # noqa: E402
+from diverse_conventions_amd.sharding import pairing_segments, segment_policy_indices   # noqa: E402
 
 
 class StackedActors:
@@ -98,6 +108,53 @@ class StackedCritics(StackedActors):
         return self.head_outputs(obs, critic_index, selected)
 
 
-def segment_policy_indices(segments, side: str) -> List[int]:
-    """Policy index per pairing segment for 'ego' or 'partner' (see sharding.pairing_segments)."""
-    return [s.ego_policy if side == "ego" else s.partner_policy for s in segments]
+class PairedRollout:
+    def __init__(self, engine: OvercookedEngine, actors: StackedActors, threads: int, n_conventions: int,
+                 ego_id: int = 0, deterministic: bool = False):
+        self.engine, self.actors, self.threads = engine, actors, threads
+        self.segments = pairing_segments(threads, n_conventions)
+        g = len(self.segments)
+        if engine.num_kitchens != g * threads:
+            raise ValueError(f"engine must hold threads*(2k+1) = {g * threads} kitchens")
+        dev = engine.device
+        self.ego_id = ego_id
+        self.idx = [None, None]
+        self.idx[ego_id] = torch.tensor(segment_policy_indices(self.segments, "ego"), device=dev)
+        self.idx[1 - ego_id] = torch.tensor(segment_policy_indices(self.segments, "partner"), device=dev)
+        self.selected = [actors.select(i) for i in self.idx]     # gathered once per pairing
+        self.deterministic = deterministic
+        self.actions = torch.zeros((2, engine.num_kitchens), dtype=torch.int64, device=dev)
+        self.logp = torch.zeros((2, engine.num_kitchens), dtype=actors.dtype, device=dev)
+        self.graph = None
+
+    def _step(self):
+        e = self.engine
+        g = len(self.segments)
+        for p in range(2):                                   # both sides, every segment, four GEMMs each
+            obs = e.obs[p].view(g, self.threads, e.width, e.height, e.obs.shape[-1])
+            a, lp = self.actors.act(obs, deterministic=self.deterministic, selected=self.selected[p])
+            self.actions[p].copy_(a.view(-1))
+            self.logp[p].copy_(lp.view(-1))
+        e.step(self.actions)                                 # int64 actions are read as they are
+
+    def step(self):
+        """One env step for all segments -> (obs, reward, done) engine buffers (overwritten next step)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step()
+        return self.engine.obs, self.engine.reward, self.engine.done
+
+    def capture(self, warmup: int = 3):
+        """Record policy GEMMs + sampling + env kernel once; replay costs one graph launch per step."""
+        self.engine.prepare_kernels()                         # nothing may compile or load a module inside the capture
+        s = torch.cuda.Stream(self.engine.device)
+        s.wait_stream(torch.cuda.current_stream(self.engine.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream(self.engine.device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        return self
