@@ -35,6 +35,39 @@ def algorithmic_bytes(S, P=2):
     return P * S * (5 * P + 10) + 2 * (4 * S + 6 * P + 4) + 4 * P + 4 * P + 4
 
 
+INFINITY_CACHE_MB = 256.0    # MI355X Infinity Cache (same guide): an in-place destination below this is absorbed on-die
+
+
+def destination(mbytes):
+    """What every in-place leg says about where its plane bytes go: a destination that fits the Infinity Cache is overwritten there
+    step after step, so its 'achieved GB/s' is fabric throughput, not HBM bandwidth."""
+    return {"destination_MB": round(mbytes, 1), "fits_infinity_cache": bool(mbytes <= INFINITY_CACHE_MB)}
+
+
+class TimedRegions:
+    """Every timed region of this file runs inside `with regions:` -- the library's hiprtc-build counter is read on both sides, and
+    the JSON line carries the sum (`jit_builds_inside_timed_regions`, 0 or the line says so loudly): a compile takes about a
+    second, a timed region is microseconds to milliseconds."""
+
+    def __init__(self):
+        from diverse_conventions_amd import native
+        self._count = native.lib().oc_debug_jit_builds
+        self.inside = 0
+        self.regions = 0
+
+    def __enter__(self):
+        self._c0 = self._count()
+        return self
+
+    def __exit__(self, *exc):
+        self.inside += self._count() - self._c0
+        self.regions += 1
+        return False
+
+    def total_builds(self):
+        return int(self._count())
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -76,6 +109,22 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
         if r > best:
             best_threads, best = c, r
     value, steps, el = rate(best_threads, budget_s, 8)
+    # SURVEY 8(d) asks for the C oracle on one core and on all cores at N = 4096 as well as at the headline's N
+    small = None
+    if kitchens != 4096:
+        acts_big, kitchens_big = acts, kitchens
+        kitchens = 4096
+        acts = rng.integers(0, 6, size=(8, 2, kitchens)).astype(np.int32)
+        s1, _, _ = rate(1, 1.0, 8)
+        sb_threads, sb = 1, s1
+        for c in candidates:
+            r, _, _ = rate(c, 0.4, 8)
+            if r > sb:
+                sb_threads, sb = c, r
+        sv, ssteps, sel = rate(sb_threads, 2.0, 64)
+        small = {"kitchens": 4096, "value": sv, "cores": sb_threads, "value_1core": s1, "unit": "agent-env steps/s",
+                 "sample": f"{ssteps} steps x 4096 kitchens ({sel:.1f} s)"}
+        acts, kitchens = acts_big, kitchens_big
     # counterpart of BASELINE config 1: one kitchen, pure-Python restatement of the reference's step + encode
     from oracle.py_oracle import PyKitchen
     kitchen = PyKitchen(params)
@@ -97,7 +146,7 @@ def cpu_baseline(params, kitchens, budget_s=10.0):
             "usable_cores": cores,
             "sample": f"{steps} steps x {kitchens} kitchens ({el:.1f} s), same layout and action law as the GPU run, "
                       f"C oracle with OpenMP over kitchens, best of {[1] + candidates} threads on a host with {cores} usable cores",
-            "value_1core": single,
+            "value_1core": single, "kitchens": kitchens, "at_4096_kitchens": small,
             "python_1env": {"value": python_1env, "cores": 1,
                             "note": "config 1 counterpart: pure-Python restatement (oracle/py_oracle.py) of the reference's "
                                     "SimplifiedOvercooked.n_step, 1 kitchen, same host"},
@@ -124,7 +173,7 @@ def check_distinct_devices(idents, allow_shared=False):
     return len(set(keys))
 
 
-def exchange_leg(world, rank, local, backend, gen, c4_step_s):
+def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
     """The one real collective of a sharded run (consumer: the reference's XP / MP losses read whole buffers,
     train/XD/xd.py:311-397): every rank's compact trajectory of BASELINE config 4 -- asymmetric_advantages, 65 536 / world
     kitchens, T = 200 steps of [state records | actions | reward | done], ONE flat int32 wire buffer that the rollout's own launches
@@ -157,18 +206,25 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
     # what the record destination saves: the same T steps with an export_states launch behind each step (round 3's way)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     scratch = torch.empty_like(traj.records[0])
-    e0.record()
-    for t in range(T):
-        eng.step(acts[t])
+    for t in range(3):                                               # warm-up of BOTH forms (round 5's line timed a hiprtc build here: the
+        eng.step(acts[t])                                            # first in-place step after steps into time-major slots, 2978 us "per step")
         eng.export_states(out=scratch)
-    e1.record()
-    torch.cuda.synchronize()
-    two_pass_us = e0.elapsed_time(e1) * 1e3 / T
-    e0.record()
-    for t in range(T):
         eng.step(acts[t], records=scratch)
-    e1.record()
     torch.cuda.synchronize()
+    with regions:
+        e0.record()
+        for t in range(T):
+            eng.step(acts[t])
+            eng.export_states(out=scratch)
+        e1.record()
+        torch.cuda.synchronize()
+    two_pass_us = e0.elapsed_time(e1) * 1e3 / T
+    with regions:
+        e0.record()
+        for t in range(T):
+            eng.step(acts[t], records=scratch)
+        e1.record()
+        torch.cuda.synchronize()
     one_pass_us = e0.elapsed_time(e1) * 1e3 / T
     del scratch
     # control plane: who is where (fails loudly when two ranks share a device and that was not asked for)
@@ -222,7 +278,8 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s):
 
     once()                                                            # warm-up: communicator set-up, allocations, code objects
     reps = 3
-    runs = [once() for _ in range(reps)]
+    with regions:
+        runs = [once() for _ in range(reps)]
     got = runs[-1][0]
     gather_ms = sum(r[1] for r in runs) / reps
     feat_ms = sum(r[2] for r in runs) / reps
@@ -392,7 +449,10 @@ def main():
     params = get_base_layout_params(args.layout, 200)
     S = params["width"] * params["height"]
     n = args.kitchens
+    torch.cuda.synchronize()                             # (the HIP context exists: what follows is the engine's own set-up)
+    t_create = time.perf_counter()
     eng = OvercookedEngine(params, n, local)
+    headline_create_ms = (time.perf_counter() - t_create) * 1e3
     if args.kpw or args.passes:
         eng.set_tuning(args.kpw, args.passes)
     gen = torch.Generator(device="cuda")
@@ -416,13 +476,18 @@ def main():
         eng.rollout(actions, args.warmup - 1)
     if args.warmup > 0:
         eng.rollout_timed(actions, 1)
+    regions = TimedRegions()
+    builds_before_timing = regions.total_builds()        # hiprtc builds of oc_create + warm-up (0 when the ahead-of-time objects match)
     barrier()
-    t0 = time.perf_counter()
-    kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0                      # this rank's K steps: from behind the opening barrier + sync to its own sync; MAX over ranks below
-    barrier()                                            # (the closing barrier: behind the clock -- with N ranks it is an all-reduce whose own latency,
-                                                         #  tens of microseconds, is not part of the K steps a 20-step run times)
+    with regions:
+        t0 = time.perf_counter()
+        kernel_ms = eng.rollout_timed(actions, args.steps)   # hipEvents on the launch stream bracket the K launches
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0                  # this rank's K steps: from behind the opening barrier + sync to its own sync; MAX over ranks below
+        barrier()                                        # (the closing barrier: behind the clock -- with N ranks it is an all-reduce whose own latency,
+        wall_with_barrier = time.perf_counter() - t0     #  tens of microseconds, is not part of the K steps a 20-step run times; the barrier-to-barrier
+                                                         #  window of rounds 1-4 travels beside it as `wall_with_barrier_ms`)
+    create_ms = {}
     fused_ms = tm_us = c4_wall = c4_kernel_ms = float("nan")
     slots, c4_total, c4_n, c4_S, c4_steps, c3 = 64, 65536, 65536 // world, 45, SEC_STEPS, None
     if not args.no_secondary:
@@ -433,10 +498,11 @@ def main():
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         eng.rollout_fused(SEC_WARMUP, actions=actions)
-        ev0.record()
-        eng.rollout_fused(SEC_STEPS, actions=actions)
-        ev1.record()
-        torch.cuda.synchronize()
+        with regions:
+            ev0.record()
+            eng.rollout_fused(SEC_STEPS, actions=actions)
+            ev1.record()
+            torch.cuda.synchronize()
         fused_ms = ev0.elapsed_time(ev1)
         # Secondary figure, never `value`: HBM proper.  The same launches with every step's observations / rewards / dones
         # written to their own time-major trajectory slot (what a rollout buffer wants): 64 slots x 52 MB are
@@ -450,11 +516,12 @@ def main():
         for _ in range(2):
             eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
         tm_rounds = max(1, SEC_STEPS // slots)
-        ev0.record()
-        for _ in range(tm_rounds):
-            eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
-        ev1.record()
-        torch.cuda.synchronize()
+        with regions:
+            ev0.record()
+            for _ in range(tm_rounds):
+                eng.rollout(actions, slots, obs=tm_obs, reward=tm_rew, done=tm_done)
+            ev1.record()
+            torch.cuda.synchronize()
         tm_us = ev0.elapsed_time(ev1) * 1e3 / (tm_rounds * slots)
         del tm_obs, tm_rew, tm_done
 
@@ -470,10 +537,11 @@ def main():
         c4_steps = SEC_STEPS
         eng4.rollout(act4, SEC_WARMUP)
         barrier()
-        t4 = time.perf_counter()
-        c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
-        torch.cuda.synchronize()
-        c4_wall = time.perf_counter() - t4
+        with regions:
+            t4 = time.perf_counter()
+            c4_kernel_ms = eng4.rollout_timed(act4, c4_steps)
+            torch.cuda.synchronize()
+            c4_wall = time.perf_counter() - t4
         barrier()
         eng4.close()
 
@@ -482,30 +550,40 @@ def main():
         c3 = None
         if world == 1:
             from diverse_conventions_amd import CLASSIC_LAYOUTS, EngineGroup
+            # cold start: oc_create of the five classic layouts at config 3's size, the first engines of these shapes in this process
+            # (module from the ahead-of-time objects, state block, tables, start-state fill) -- VERDICT r05 item 7 asks for < 50 ms each
+            for name in CLASSIC_LAYOUTS:
+                tc = time.perf_counter()
+                e_cs = OvercookedEngine(get_base_layout_params(name, 200), 8192, local)
+                create_ms[name] = {"ms": (time.perf_counter() - tc) * 1e3, "kernel_build": e_cs.kernel_build_info.split("; ")[-1].rstrip(")")}
+                e_cs.close()
             grp = EngineGroup.from_layouts(CLASSIC_LAYOUTS, 8192, local)
             act3 = [torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32) for _ in grp.engines]
             grp.rollout_timed(act3, SEC_WARMUP)
             c3_steps = SEC_STEPS
-            c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
+            with regions:
+                c3_us = grp.rollout_timed(act3, c3_steps) * 1e3 / c3_steps
             c3_bytes = sum(algorithmic_bytes(e.size) * e.num_kitchens for e in grp.engines)
             c3 = {"what": "BASELINE config 3 env step: 5 classic layouts x 8192 kitchens, ONE launch per joint step (oc_group_step)",
                   "steps": c3_steps, "us_per_joint_step": c3_us, "value": 2 * 5 * 8192 / c3_us * 1e6, "unit": "agent-env steps/s",
                   "bytes_per_launch": c3_bytes, "achieved_GBps": c3_bytes / c3_us / 1e3, "frac_of_8TBps": c3_bytes / c3_us / 1e3 / HBM_PEAK_GBS,
-                  "build": grp.build_info}
+                  **destination(sum(2 * e.num_kitchens * e.size * 20 for e in grp.engines) / 1e6), "build": grp.build_info}
             grp.close(close_engines=True)
 
     # every rank's timings -> the slowest rank's (MAX), as the contract asks for `value`
-    stats = torch.tensor([wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms], dtype=torch.float64,
+    stats = torch.tensor([wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms, wall_with_barrier], dtype=torch.float64,
                          device="cuda" if backend == "nccl" else "cpu")
     if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms = (float(x) for x in stats)
+    wall, kernel_ms, fused_ms, tm_us, c4_wall, c4_kernel_ms, wall_with_barrier = (float(x) for x in stats)
     fused_bytes = n * (2 * S * 20 + 8 + 8 + 4)            # obs + i32 actions + reward + done; no state round trip
     fused = {"what": "same steps as one launch (state resident in LDS), action tape in HBM, outputs in place",
              "steps": SEC_STEPS, "us_per_step": fused_ms * 1e3 / SEC_STEPS, "value": 2 * n * world * SEC_STEPS / (fused_ms / 1e3),
              "unit": "agent-env steps/s", "bytes_per_step": fused_bytes,
              "achieved_GBps": fused_bytes / (fused_ms / 1e3 / SEC_STEPS) / 1e9,
-             "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / SEC_STEPS) / 1e9 / HBM_PEAK_GBS}
+             "frac_of_8TBps": fused_bytes / (fused_ms / 1e3 / SEC_STEPS) / 1e9 / HBM_PEAK_GBS, **destination(2 * n * S * 20 / 1e6),
+             "note": "the 52 MB in-place destination lives in the 256 MB Infinity Cache: this is on-die fabric throughput, not HBM bandwidth "
+                     "(HBM's achievable rate is ~6.3 TB/s = 0.79; the HBM-proper figure of this workload is roofline.frac_hbm_proper)"}
     hbm_proper = {"what": f"the headline workload with every step's outputs written to their own time-major slot ({slots} slots, "
                           f"{slots * 2 * n * S * 20 / 1e9:.1f} GB: beyond the 256 MB Infinity Cache), one launch per step, non-temporal plane stores",
                   "steps": max(1, SEC_STEPS // slots) * slots, "us_per_launch": tm_us, "value": 2 * n * world / tm_us * 1e6, "unit": "agent-env steps/s",
@@ -516,13 +594,13 @@ def main():
                      "steps": c4_steps, "kitchens_per_gpu": c4_n, "us_per_launch": c4_us, "value": 2 * c4_n * world * c4_steps / c4_wall,
                      "unit": "agent-env steps/s", "scaling": "strong",
                      "achieved_GBps_per_gpu": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3,
-                     "frac_of_8TBps": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3 / HBM_PEAK_GBS}
+                     "frac_of_8TBps": algorithmic_bytes(c4_S) * c4_n / c4_us / 1e3 / HBM_PEAK_GBS, **destination(2 * c4_n * c4_S * 20 / 1e6)}
 
     # Secondary figure, never `value`: the per-update trajectory exchange -- the one place the north star's collective meets a
     # clock.  Runs whenever a process group exists (world > 1, or OC_BENCH_FORCE_DIST=1 with one rank).
     exchange = None
     if use_dist and not args.no_secondary:
-        exchange = exchange_leg(world, rank, local, backend, gen, c4_wall / c4_steps)
+        exchange = exchange_leg(world, rank, local, backend, gen, c4_wall / c4_steps, regions)
 
     # Secondary figure, never `value`: policies in the loop.  8 conventions in the reference's 15 pairing
     # segments, every actor on both sides evaluated by ONE fused MFMA launch (oc_policy_forward) per step + the env launch;
@@ -547,11 +625,12 @@ def main():
           torch.cuda.synchronize()
           psteps = SEC_STEPS
           pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-          pe0.record()
-          for _ in range(psteps):
-              ro.plan.forward(eng2.obs, actions=ro.actions, action_logp=ro.logp, seed=0, counter=0, device_counter=ro.draw)
-          pe1.record()
-          torch.cuda.synchronize()
+          with regions:
+              pe0.record()
+              for _ in range(psteps):
+                  ro.plan.forward(eng2.obs, actions=ro.actions, action_logp=ro.logp, seed=0, counter=0, device_counter=ro.draw)
+              pe1.record()
+              torch.cuda.synchronize()
           pol_us = pe0.elapsed_time(pe1) * 1e3 / psteps
           # the whole step: a policy launch and an env launch, every launch of every step enqueued from C by one call (the env step
           # folded INTO the policy launch was built and measured in round 3 -- 116 against 60 us per step -- and lives behind the
@@ -561,10 +640,11 @@ def main():
           torch.cuda.synchronize()
           step_modes["two_launches"] = float("inf")
           for _ in range(2):                             # (best of two, as for the share leg below)
-              t1 = time.perf_counter()
-              ro.step(psteps)
-              torch.cuda.synchronize()
-              step_modes["two_launches"] = min(step_modes["two_launches"], (time.perf_counter() - t1) / psteps * 1e6)
+              with regions:
+                  t1 = time.perf_counter()
+                  ro.step(psteps)
+                  torch.cuda.synchronize()
+                  step_modes["two_launches"] = min(step_modes["two_launches"], (time.perf_counter() - t1) / psteps * 1e6)
           step_us = step_modes["two_launches"]
           # ... and what training does: the same two launches per step, every step's planes into their own time-major slot
           # (TrajectoryBuffer; the fresh planes are stored plainly while the rollout runs -- the next launch reads them)
@@ -572,11 +652,12 @@ def main():
           ctraj = TrajectoryBuffer(eng2, 200)
           ro.collect(ctraj)
           torch.cuda.synchronize()
-          t1 = time.perf_counter()
-          for _ in range(3):
-              ro.collect(ctraj)
-          torch.cuda.synchronize()
-          step_modes["two_launches_time_major_slots"] = (time.perf_counter() - t1) / 600 * 1e6
+          with regions:
+              t1 = time.perf_counter()
+              for _ in range(3):
+                  ro.collect(ctraj)
+              torch.cuda.synchronize()
+              step_modes["two_launches_time_major_slots"] = (time.perf_counter() - t1) / 600 * 1e6
           del ctraj
           rows = 2 * eng2.num_kitchens
           cycles = rows / 32 * 32 * (P * (6 * nets.digits + 12) + 24 + 12)     # MFMA issue cycles (i8 conv digits + f16 two-piece products), DESIGN 9a
@@ -624,10 +705,11 @@ def main():
           torch.cuda.synchronize()
           share_us = float("inf")
           for _ in range(2):                             # (best of two: 2 x SEC_STEPS launches of ~20 us each are enqueued by the host as they run,
-              t3 = time.perf_counter()                   #  and a descheduled host thread shows up as GPU idle time -- one driver-style run read 79.8 us)
-              ro3.step(SEC_STEPS)
-              torch.cuda.synchronize()
-              share_us = min(share_us, (time.perf_counter() - t3) / SEC_STEPS * 1e6)
+              with regions:                              #  and a descheduled host thread shows up as GPU idle time -- one driver-style run read 79.8 us)
+                  t3 = time.perf_counter()
+                  ro3.step(SEC_STEPS)
+                  torch.cuda.synchronize()
+                  share_us = min(share_us, (time.perf_counter() - t3) / SEC_STEPS * 1e6)
           share = {"what": f"BASELINE config 4, one GPU's share of 8: asymmetric_advantages, {eng3.num_kitchens} kitchens, {sk + 1} conventions in {sG} "
                            f"pairing segments of {sthreads} kitchens, every actor and one critic per segment on both sides in ONE fused MFMA launch "
                            "per step + the env launch, all steps enqueued by one call; random-weight reference-shape networks",
@@ -649,19 +731,21 @@ def main():
         eng_c2 = OvercookedEngine(c2_params, c2_n, local)
         act_c2 = torch.randint(0, 6, (t_act, 2, c2_n), generator=gen, device="cuda", dtype=torch.int32)
         eng_c2.rollout(act_c2, SEC_WARMUP)
-        c2_us = eng_c2.rollout_timed(act_c2, SEC_STEPS) * 1e3 / SEC_STEPS
+        with regions:
+            c2_us = eng_c2.rollout_timed(act_c2, SEC_STEPS) * 1e3 / SEC_STEPS
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         eng_c2.rollout_fused(SEC_WARMUP, actions=act_c2)
-        ev0.record()
-        eng_c2.rollout_fused(SEC_STEPS, actions=act_c2)
-        ev1.record()
-        torch.cuda.synchronize()
+        with regions:
+            ev0.record()
+            eng_c2.rollout_fused(SEC_STEPS, actions=act_c2)
+            ev1.record()
+            torch.cuda.synchronize()
         c2_fused_us = ev0.elapsed_time(ev1) * 1e3 / SEC_STEPS
         c2_bytes = algorithmic_bytes(20) * c2_n
         config2 = {"what": "BASELINE config 2: cramped_room, 4096 parallel kitchens, random-action rollout, step + encode kernel only",
                    "steps": SEC_STEPS, "kitchens": c2_n, "us_per_launch": c2_us, "value": 2 * c2_n / c2_us * 1e6, "unit": "agent-env steps/s",
                    "bytes_per_launch": c2_bytes, "achieved_GBps": c2_bytes / c2_us / 1e3, "frac_of_8TBps": c2_bytes / c2_us / 1e3 / HBM_PEAK_GBS,
-                   "kernel_build": eng_c2.kernel_build_info,
+                   **destination(2 * c2_n * 20 * 20 / 1e6), "kernel_build": eng_c2.kernel_build_info,
                    "fused_rollout_us_per_step": c2_fused_us, "fused_rollout_value": 2 * c2_n / c2_fused_us * 1e6,
                    "note": "one launch per step is launch-bound at this size (a wavefront's own critical path is ~3.4 us, DESIGN.md 5); the "
                            "K-steps-per-launch rollout has no launch boundary per step"}
@@ -681,11 +765,13 @@ def main():
               eng_np = OvercookedEngine(npp, nn, local)
               act_np = torch.randint(0, 6, (t_act, nP, nn), generator=gen, device="cuda", dtype=torch.int32)
               eng_np.rollout(act_np, 50)
-              np_us = min(eng_np.rollout_timed(act_np, SEC_STEPS // 2) for _ in range(2)) * 1e3 / (SEC_STEPS // 2)
+              with regions:
+                  np_us = min(eng_np.rollout_timed(act_np, SEC_STEPS // 2) for _ in range(2)) * 1e3 / (SEC_STEPS // 2)
               np_bytes = nn * (nP * nS * (5 * nP + 10) + 2 * eng_np.record_bytes + 8 * nP + 4)
               nplayer["cases"].append({"layout": np_layout, "players": nP, "kitchens": nn, "us_per_launch": np_us, "value": nP * nn / np_us * 1e6,
                                        "unit": "agent-env steps/s", "bytes_per_launch": np_bytes, "achieved_GBps": np_bytes / np_us / 1e3,
-                                       "frac_of_8TBps": np_bytes / np_us / 1e3 / HBM_PEAK_GBS, "kernel_build": eng_np.kernel_build_info})
+                                       "frac_of_8TBps": np_bytes / np_us / 1e3 / HBM_PEAK_GBS, **destination(nn * nP * nS * (5 * nP + 10) / 1e6),
+                                       "kernel_build": eng_np.kernel_build_info})
               eng_np.close()
               del act_np
       except Exception as exc:                             # noqa: BLE001
@@ -716,10 +802,11 @@ def main():
           mro = MixedPlayRollout(meng, mnets, mL, main=(0, 2), partner=(1, 3), seed=3)
           mro.collect()
           torch.cuda.synchronize()
-          t5 = time.perf_counter()
-          mro.collect()
-          torch.cuda.synchronize()
-          m_s = time.perf_counter() - t5
+          with regions:
+              t5 = time.perf_counter()
+              mro.collect()
+              torch.cuda.synchronize()
+              m_s = time.perf_counter() - t5
           # outside the timed region: 3 x 48 kitchens (first, middle, last roles of the staircase) through the oracle
           m_ok, per = True, 48
           for f in (0, (mn - per) // 2, mn - per):
@@ -753,7 +840,7 @@ def main():
               port = sock.getsockname()[1]
           dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", local))
           try:
-              exchange = exchange_leg(1, 0, local, "nccl", gen, c4_wall / c4_steps)
+              exchange = exchange_leg(1, 0, local, "nccl", gen, c4_wall / c4_steps, regions)
           finally:
               dist.destroy_process_group()
       except Exception as exc:                             # noqa: BLE001
@@ -791,6 +878,13 @@ def main():
             "timing": "per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; ms_per_step and value from the MAX over ranks",
 
             "ms_per_step": wall * 1e3 / args.steps,
+            # what the wall clock adds to the kernels' own time over the K-step region (enqueue, the two syncs, the clock reads): a 20-step
+            # run is 220 us of kernels, so tens of microseconds of host cost move `value` by tens of percent from box to box (profiles/README.md)
+            "kernel_ms_total": kernel_ms, "host_fixed_us": wall * 1e6 - kernel_ms * 1e3,
+            "value_kernel_time": 2 * n * world * args.steps / (kernel_ms / 1e3),
+            "wall_with_barrier_ms": wall_with_barrier * 1e3,
+            "wall_with_barrier_note": "rounds 1-4 timed barrier-to-barrier (the closing all-reduce inside the clock); `value` stops each rank's clock "
+                                      "at its own synchronize -- compare like with like across rounds",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.layout}, {n} kitchens per GPU, 2 agents, uniform random joint actions "
@@ -799,6 +893,12 @@ def main():
                        "layout": args.layout, "kitchens_per_gpu": n, "parallelism": f"kitchen-shard x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_hbm_proper": None if args.no_secondary else hbm_proper["frac_of_8TBps"],
+                         **destination(2 * n * S * 20 / 1e6),
+                         "bound_note": "the reference's data-plane contract is an in-place output buffer (52 MB at this size): it is overwritten in the "
+                                       "256 MB Infinity Cache, so `frac` is the step's throughput against the HBM peak, not measured HBM bandwidth; with "
+                                       "every step in its own time-major slot (3.4 GB, nothing absorbed on-die) the same launch reaches `frac_hbm_proper`; "
+                                       "HBM's achievable rate is ~0.79 of the peak",
                          "kernel": "oc_jit_step_i32_v16" if "specialised" in build_info else "oc_step_kernel<STEP,i32,vec16>",
                          "kernel_build": build_info, "bytes_per_launch": bytes_per_launch,
                          "us_per_launch": per_launch_s * 1e6, "kernel_us_profile": kernel_us_profile,
@@ -828,6 +928,16 @@ def main():
             out["config4_share_policy_in_loop"] = share
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, n)
+        out["cold_start"] = {"headline_oc_create_ms": headline_create_ms, "oc_create_ms_8192_kitchens": create_ms,
+                             "note": "wall time of OvercookedEngine(...) = oc_create: module load (ahead-of-time code object, else disk cache, else a "
+                                     "hiprtc build of about a second), device buffers, tables, start-state fill and one device synchronize"}
+        out["jit_builds_inside_timed_regions"] = int(regions.inside)
+        out["jit_builds"] = {"before_the_headline_region": int(builds_before_timing), "whole_process": regions.total_builds(),
+                             "timed_regions": regions.regions,
+                             "note": "hiprtc compilations (about a second each): 0 in the whole process when the ahead-of-time code objects "
+                                     "(csrc/aot, built by __graft_entry__.build()) match the box; never inside a timed region"}
+        if regions.inside:
+            print(f"bench.py: {regions.inside} hiprtc build(s) ran INSIDE a timed region -- a figure of this line is a compile time", file=sys.stderr)
         print(json.dumps(out), file=real_stdout, flush=True)
     eng.close()
     if use_dist:

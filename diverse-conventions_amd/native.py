@@ -64,7 +64,7 @@ SYMBOLS = SYMBOLS_ENV + SYMBOLS_OPS
 # and include/overcooked_debug.h (diagnostics)
 SYMBOLS_EXPERIMENTS = ["oc_exp_cu_partition_create", "oc_exp_cu_partition_destroy", "oc_exp_policy_forward_cus", "oc_exp_set_cu_budget",
                        "oc_exp_group_policy_rollout_streams"]
-SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group"]
+SYMBOLS_DEBUG = ["oc_debug_jit_compile", "oc_debug_jit_compile_group", "oc_debug_jit_builds", "oc_debug_aot_build", "oc_debug_aot_build_group"]
 SYMBOLS_DIAG = ["oc_debug_trace", "oc_policy_debug_trace", "oc_debug_fold_launches"]       # exported by the diagnostics build only
 
 
@@ -250,6 +250,10 @@ def lib():
     L.oc_debug_jit_compile.argtypes = [ctypes.POINTER(OcLayoutParams), i64, ctypes.c_char_p, ctypes.POINTER(i64),
                                        ctypes.c_char_p, i64]
     L.oc_abi_version.argtypes = []
+    L.oc_debug_jit_builds.argtypes = []
+    L.oc_debug_aot_build.argtypes = [ctypes.POINTER(OcLayoutParams), i64, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32)]
+    L.oc_debug_aot_build_group.argtypes = [ctypes.POINTER(OcLayoutParams), ctypes.POINTER(i64), ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_char_p]
+    L.oc_debug_jit_builds.restype = ctypes.c_longlong
     L.oc_encode_trajectory.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp]
     pvp = ctypes.POINTER(vp)
     L.oc_group_create.argtypes = [pvp, ctypes.c_int32, pvp]
@@ -275,6 +279,46 @@ def lib():
 def check(status):
     if status != OC_OK:
         raise OvercookedNativeError(status, lib().oc_last_error().decode())
+
+
+AOT_DIR = os.path.join(CSRC, "aot")                                   # where the library looks (next to itself)
+AOT_ARCH = "gfx950:sramecc+:xnack-"                                  # hipDeviceProp_t::gcnArchName of an MI355X
+
+
+def aot_build(shapes=None, groups=None, arch=AOT_ARCH, out_dir=AOT_DIR, verbose=False):
+    """Ahead-of-time code objects for the BASELINE shapes (no GPU needed): `shapes` = [(layout params, kitchens)], `groups` =
+    [[(layout params, kitchens), ...]].  -> number of code objects in out_dir afterwards.  Defaults: see aot_default_shapes()."""
+    from .layouts import get_base_layout_params
+    if shapes is None or groups is None:
+        d_shapes, d_groups = aot_default_shapes()
+        shapes = d_shapes if shapes is None else shapes
+        groups = d_groups if groups is None else groups
+    L = lib()
+    os.makedirs(out_dir, exist_ok=True)
+    for params, n in shapes:
+        cnt = ctypes.c_int32(0)
+        check(L.oc_debug_aot_build(ctypes.byref(make_params(params)), int(n), arch.encode(), out_dir.encode(), ctypes.byref(cnt)))
+        if verbose:
+            print(f"aot: {params.get('name', '?')} x {n}: {cnt.value} modules")
+    for grp in groups:
+        arr = (OcLayoutParams * len(grp))(*[make_params(p) for p, _ in grp])
+        counts = (ctypes.c_int64 * len(grp))(*[int(k) for _, k in grp])
+        check(L.oc_debug_aot_build_group(arr, counts, len(grp), 256, arch.encode(), out_dir.encode()))
+    return len([f for f in os.listdir(out_dir) if f.endswith(".hsaco")])
+
+
+def aot_default_shapes():
+    """What BASELINE.json's configs and bench.py's legs create: the five classic layouts at 65 536 and 8192 kitchens, cramped_room at
+    4096 (config 2) and at the policies-in-the-loop shapes, config 4's per-GPU share, the config-3 group."""
+    from .layouts import CLASSIC_LAYOUTS, get_base_layout_params
+    P = lambda name, h=200: dict(get_base_layout_params(name, h), name=name)
+    shapes = []
+    for name in CLASSIC_LAYOUTS:
+        shapes += [(P(name), 65536), (P(name), 8192)]
+    shapes += [(P("cramped_room"), 4096), (P("cramped_room"), 65535), (P("cramped_room"), 1000), (P("cramped_room"), 65471),
+               (P("asymmetric_advantages"), 8184), (P("asymmetric_advantages"), 65536 // 2), (P("asymmetric_advantages"), 65536 // 4)]
+    groups = [[(P(name), 8192) for name in CLASSIC_LAYOUTS]]
+    return shapes, groups
 
 
 def jit_compile_check(params, num_kitchens=4096, arch="gfx950"):

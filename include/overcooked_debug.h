@@ -22,6 +22,17 @@ int oc_debug_jit_compile(const oc_layout_params *p, int64_t n_kitchens, const ch
  * plan_out (optional, 2 * n_engines ints): kitchens per wavefront group and blocks of every engine. */
 int oc_debug_jit_compile_group(const oc_layout_params *params, const int64_t *n_kitchens, int32_t n_engines, int32_t num_cus, const char *arch,
                                int64_t *code_bytes, int32_t *plan_out, char *log_out, int64_t log_cap);
+/* Ahead-of-time builds (no GPU needed; __graft_entry__.build() calls them for the BASELINE shapes): every hiprtc module an engine of
+ * this shape / a group of these engines loads, compiled for `arch` as the device reports it ("gfx950:sramecc+:xnack-") and written to
+ * out_dir/<hash>.hsaco.  The library looks in <its own directory>/aot/ before it compiles anything (oc_kernel_build_info then says
+ * "ahead of time").  *n_modules (optional): code objects written for the engine. */
+int oc_debug_aot_build(const oc_layout_params *params, int64_t n_kitchens, const char *arch, const char *out_dir, int32_t *n_modules);
+int oc_debug_aot_build_group(const oc_layout_params *params, const int64_t *n_kitchens, int32_t n_engines, int32_t num_cus, const char *arch,
+                             const char *out_dir);
+/* hiprtc compilations this process has run so far (code objects found in the process / ahead-of-time / disk caches do not count):
+ * a compilation takes about a second, so a caller that times something reads this before and after to prove that none happened
+ * inside its timed region (bench.py: `jit_builds_inside_timed_regions`). */
+long long oc_debug_jit_builds(void);
 #ifdef OC_DIAGNOSTICS
 /* Per-wavefront phase stamps (s_memrealtime) of the step kernel's next launches (tools/trace_phases.py).  enable != 0: allocate
  * and zero the trace buffer; 0: copy [max_waves][16] stamps to host_out (may be NULL) and free it. */

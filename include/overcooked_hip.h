@@ -220,7 +220,16 @@ int oc_set_tuning(oc_engine *e, int kitchens_per_wave, int passes_per_flush, int
 /* Build NOW what is otherwise compiled on first use -- the step kernels for fresh (time-major) destinations and the
  * K-steps-per-launch rollout kernels (hiprtc + module load, about a second each the first time, from the code-object cache
  * afterwards).  Call it before capturing oc_step / oc_rollout* into a HIP graph: a first use inside a capture would compile and
- * load a module there.  A build that fails is remembered and the generic kernel serves (results are identical). */
+ * load a module there.  A build that fails is remembered and the generic kernel serves (results are identical).
+ * Memory: an engine whose viewer planes are no multiple of 64 bytes (n_kitchens x tiles x 20 % 64 != 0) gets a SECOND record block
+ * (n_kitchens x oc_state_record_bytes()) with that build -- its steps into fresh destinations read one block and write the other and
+ * the two swap roles (the neighbour's last kitchen is stepped as a halo; if the allocation is refused the launches run without halo
+ * kitchens: same results, and oc_kernel_build_info says so).
+ * Graph capture: the record block's address is a kernel argument, so from the FIRST capture of any entry point of an engine on,
+ * that engine's blocks never swap again -- graph replays and eager calls may then be mixed freely (tests/test_hip_parity.py:
+ * capture, eager steps into fresh slots, replay); the price is that its later steps into fresh destinations run without halo kitchens
+ * (~14.1 -> 18.3 us per step at 65 535 cramped_room kitchens).  Capture on an engine before its first eager fresh-destination step,
+ * or not at all, if that matters. */
 int oc_prepare_kernels(oc_engine *e);
 
 /* Which kernel build serves this engine: "specialised for gfx950..." when the per-engine hiprtc build

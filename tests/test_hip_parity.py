@@ -728,3 +728,58 @@ def test_a_captured_step_into_a_fresh_slot_replays_without_halo_kitchens():
     for x, y in zip(eng.get_state(), ora.get_state()):
         assert np.array_equal(x, y)
     eng.close()
+
+
+def test_capture_then_an_eager_step_into_a_fresh_slot_then_replay():
+    """The advisor's round-5 sequence: a graph is captured (its kernel arguments hold the record block's address), then an EAGER step goes
+    into a fresh destination -- the launch that used to swap the record blocks -- then the graph is replayed.  From the first capture on
+    the engine's blocks never swap (note_stream / halo_state_out in overcooked_engine.hip: such launches then run without halo kitchens),
+    so graph and eager calls keep stepping the same kitchens: every replay, every eager step and the final records against the oracle."""
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+    params = get_base_layout_params("cramped_room", 30)
+    n = 49155                                                # planes start off 64-byte boundaries: the module for fresh destinations has halo kitchens
+    eng = OvercookedEngine(params, n, 0)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    eng.prepare_kernels()
+    a = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    slots = torch.zeros((3, 2, n, params["width"], params["height"], 20), dtype=torch.int8, device="cuda")
+    rew = torch.zeros((2, n), dtype=torch.int32, device="cuda")
+    done = torch.zeros(n, dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def draw():
+        a.copy_(torch.randint(0, 6, (2, n), device="cuda", dtype=torch.int32, generator=g))
+        return a.cpu().numpy()
+
+    def check(obs, where):
+        oobs, orew, odone = ora.step(host_a)
+        assert np.array_equal(obs.cpu().numpy(), oobs), where
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done.cpu().numpy().astype(bool), np.asarray(odone).astype(bool)), where
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for i in range(3):                                   # eager, before any capture: halo launches that swap the blocks (an odd number: the blocks end up swapped)
+            host_a = draw()
+            eng.step(a, obs=slots[i % 2], reward=rew, done=done)
+            check(slots[i % 2], ("eager before", i))
+    torch.cuda.current_stream().wait_stream(s)
+    host_a = draw()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.step(a, obs=slots[0], reward=rew, done=done)    # (capture enqueues nothing: the oracle steps at the replays)
+    for rnd in range(3):
+        host_a = draw()
+        graph.replay()
+        check(slots[0], ("replay", rnd))
+        for j in (1, 2):                                     # eager steps into destinations that differ from the previous step's: fresh slots
+            host_a = draw()
+            eng.step(a, obs=slots[j], reward=rew, done=done)
+            check(slots[j], ("eager after capture", rnd, j))
+        assert torch.equal(eng.export_states(), eng.export_states())
+    host_a = draw()
+    graph.replay()
+    check(slots[0], "last replay")
+    for x, y in zip(eng.get_state(), ora.get_state()):
+        assert np.array_equal(x, y)
+    eng.close()
