@@ -194,3 +194,15 @@ def best_partner(scores: torch.Tensor, n_conventions: int, xp_weight: float = 1.
 def segment_policy_indices(segments, side: str) -> list:
     """Policy index per pairing segment for 'ego' or 'partner' (see sharding.pairing_segments)."""
     return [s.ego_policy if side == "ego" else s.partner_policy for s in segments]
+
+
+def segment_critics(segments, side: str) -> list:
+    """Which critic VALUES each pairing segment on a side while the reference collects (pinned to its own runner by
+    tests/golden/pairing_cases.npz): the convention being trained always brings its own current critic ("new": `policy.get_actions`,
+    train/XD/xd_player.py:94,190-197 and :76-77), a frozen convention i on the ego side is wrapped with `xp_critic0[i]`
+    (xd_player.py:92), on the partner side with `xp_critic1[i]` (xd_player.py:74).  -> ["new" | ("xp0", i) | ("xp1", i)] per segment."""
+    out = []
+    for s in segments:
+        pol = s.ego_policy if side == "ego" else s.partner_policy
+        out.append("new" if pol == 0 else (("xp0" if side == "ego" else "xp1"), pol - 1))
+    return out

@@ -129,12 +129,20 @@ class TrajectoryBuffer:
         """Mean return of the episodes that ENDED inside the buffer, per kitchen -> (mean f32 [N], count int64 [N]); NaN where
         none ended.  What the reference's runners accumulate as `running_score` and push into `scores` at every done
         (train/XD/xd_player.py:224-230); feed it to `sharding.segment_scores`.  Assumes slot 0 starts an episode."""
-        r = self.reward[:self.t, 0].to(torch.float32)                 # the shared reward (sum over players)
-        d = self.done[:self.t].to(torch.float32)
-        upto_last_done = (r.cumsum(0) * d).amax(0)                     # rewards are never negative
-        count = d.sum(0)
-        return upto_last_done / count, count.to(torch.int64)
+        return episode_returns_of(self.reward[:self.t, 0], self.done[:self.t])      # the shared reward (sum over players)
 
     def agent_view(self, agent: int):
         """Observations of one player as the reference buffer indexes them: [T+1, N, W, H, C] (int8 view)."""
         return self.obs[:, agent]
+
+
+def episode_returns_of(reward, done):
+    """reward [T, N], done [T, N] (any numeric dtype) -> (mean return of the episodes that ended inside the T steps f32 [N], their
+    count int64 [N]); NaN where none ended.  The reference adds every step's reward to `running_score`, pushes it into the segment's
+    score list at a done and zeroes it (train/XD/xd_player.py:217-230): the sum of those pushes is the reward total up to the last
+    done.  Pinned to the reference's own lists by tests/test_pairing_golden.py.  Rewards must not be negative (Overcooked's are not)."""
+    r = reward.to(torch.float32)
+    d = done.to(torch.float32)
+    upto_last_done = (r.cumsum(0) * d).amax(0)
+    count = d.sum(0)
+    return upto_last_done / count, count.to(torch.int64)
