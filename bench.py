@@ -395,6 +395,164 @@ def check_policy_in_loop(ro, eng, params, T=24, blocks=4, per_block=64):
     return True
 
 
+def drop_in_and_eval_legs(local, regions, gen):
+    """Two secondaries about the surface the north star promises: the reference's training loop calls
+    `env.step(ego_action)` once per step from Python (pantheonrl_extension/vectorenv.py:171-200, train/MAPPO/main_player.py:211-277),
+    not a C-enqueued run of launches.
+      drop_in_step: microseconds per OvercookedMadrona.step() -- ego actions already on the GPU -- with a RandomVectorAgent partner and
+                    with an eager-PyTorch R_Actor partner (the reference's network, utils/cnn.py:26-38), at 65 536 and 8192 kitchens,
+                    beside the env kernel's own time and the host's share (the loop's enqueue time before the final synchronize);
+      eval_1000:    the authors' evaluation shape (train/testing.py:39-59): 1000 kitchens x 200 steps, two decentralised policies
+                    (here both through FusedVectorAgent), reward / 20 accumulated; the recorded actions replayed through the CPU
+                    oracle afterwards (rewards and dones bit-identical)."""
+    import numpy as np
+    import torch
+    from diverse_conventions_amd import FusedVectorAgent, OvercookedMadrona, PackedNetworks, RandomVectorAgent, VectorAgent, get_base_layout_params
+    from oracle import oracle
+    W, H = 5, 4
+    P = (W - 2) * (H - 2)
+    g0 = torch.Generator().manual_seed(7)
+    r = lambda *sh: torch.randn(*sh, generator=g0) * 0.1
+    sds = [{"base.cnn.cnn.0.weight": r(32, 20, 3, 3), "base.cnn.cnn.0.bias": r(32), "base.cnn.cnn.3.weight": r(64, 32 * P),
+            "base.cnn.cnn.3.bias": r(64), "base.cnn.cnn.5.weight": r(64, 64), "base.cnn.cnn.5.bias": r(64),
+            "act.action_out.linear.weight": r(6, 64), "act.action_out.linear.bias": r(6)} for _ in range(2)]
+
+    class TorchActor(VectorAgent):
+        """the reference's R_Actor as plain eager PyTorch: CNNLayer (conv 3x3 -> ReLU -> flatten -> Linear -> ReLU -> Linear -> ReLU) +
+        Categorical head, sampled (train/MAPPO/utils/cnn.py:26-41, utils/act.py:41-80).  The 3x3 valid convolution is applied as one
+        dense matrix over the flattened (W, H, C) row -- the same linear map, without a MIOpen kernel search on a fresh box."""
+
+        def __init__(self, sd, dev):
+            cw = sd["base.cnn.cnn.0.weight"]                             # [O, C, 3, 3], multiplies input tile (x + kx, y + ky)
+            dense = torch.zeros((W, H, 20, 32, W - 2, H - 2))            # -> output (o, x', y'): the flatten order of the reference
+            for x in range(W - 2):
+                for y in range(H - 2):
+                    dense[x:x + 3, y:y + 3, :, :, x, y] = cw.permute(2, 3, 1, 0)
+            self.w0 = dense.reshape(W * H * 20, 32 * P).to(dev)
+            self.b0 = sd["base.cnn.cnn.0.bias"].repeat_interleave(P).to(dev)
+            self.w1, self.b1 = sd["base.cnn.cnn.3.weight"].t().contiguous().to(dev), sd["base.cnn.cnn.3.bias"].to(dev)
+            self.w2, self.b2 = sd["base.cnn.cnn.5.weight"].t().contiguous().to(dev), sd["base.cnn.cnn.5.bias"].to(dev)
+            self.w3, self.b3 = sd["act.action_out.linear.weight"].t().contiguous().to(dev), sd["act.action_out.linear.bias"].to(dev)
+
+        def logits(self, obs):
+            x = obs.reshape(obs.shape[0], -1).float()
+            x = torch.relu(torch.addmm(self.b0, x, self.w0))
+            x = torch.relu(torch.addmm(self.b1, x, self.w1))
+            x = torch.relu(torch.addmm(self.b2, x, self.w2))
+            return torch.addmm(self.b3, x, self.w3)
+
+        @torch.no_grad()
+        def get_action(self, obs, record=True):
+            return torch.distributions.Categorical(logits=self.logits(obs.obs)).sample().unsqueeze(-1)
+
+        def update(self, rewards, dones):
+            pass
+
+    drop = {"what": "microseconds per OvercookedMadrona.step(ego_action) called from Python as the reference's runner does "
+                    "(vectorenv.py:171-200): partner.get_action, the [P, N, 1] action assembly, ONE fused env launch, the ego view; ego "
+                    "actions resident on the GPU; cramped_room", "cases": []}
+    T, t_act = 400, 64
+    for n in (65536, 8192):
+        env = OvercookedMadrona("cramped_room", n, local, debug_compile=False)
+        dev = env.sim.device
+        ego = torch.randint(0, 6, (t_act, n, 1), generator=gen, device=dev, dtype=torch.int64)
+        par = torch.randint(0, 6, (t_act, n, 1), generator=gen, device=dev, dtype=torch.int64)
+        # the env kernel alone at this size, C-enqueued
+        flat = torch.randint(0, 6, (t_act, 2, n), generator=gen, device=dev, dtype=torch.int32)
+        env.sim.rollout(flat, 50)
+        with regions:
+            kern_us = env.sim.rollout_timed(flat, 500) * 1e3 / 500
+        case = {"kitchens": n, "env_kernel_us": kern_us}
+        for name in ("random_partner", "torch_actor_partner"):
+            tick = [0]
+            agent = RandomVectorAgent(lambda: par[tick[0] % t_act]) if name == "random_partner" else TorchActor(sds[1], dev)
+            env.partners[0].clear()
+            env.add_partner_agent(agent)
+            env.reset()
+            for t in range(60):
+                tick[0] = t
+                env.step(ego[t % t_act])
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(2):
+                with regions:
+                    t0 = time.perf_counter()
+                    for t in range(T):
+                        tick[0] = t
+                        env.step(ego[t % t_act])
+                    t1 = time.perf_counter()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                cur = {"us_per_step": (t2 - t0) / T * 1e6, "host_enqueue_us_per_step": (t1 - t0) / T * 1e6}
+                best = cur if best is None or cur["us_per_step"] < best["us_per_step"] else best
+            best["x_env_kernel"] = best["us_per_step"] / kern_us
+            best["value"] = 2 * n / best["us_per_step"] * 1e6
+            case[name] = best
+        env.close()
+        drop["cases"].append(case)
+    drop["note"] = ("host-bound when host_enqueue_us_per_step ~ us_per_step: the Python of one step (partner call, torch.stack into the "
+                    "persistent [P, N, 1] buffer, one ctypes call, cached ego view) costs more than the kernel; the C-enqueued loops of this "
+                    "line (`value`, policy_in_loop) are what a runner that hands the loop to the library gets")
+
+    # ---- eval_1000: train/testing.py:39-59
+    n, L = 1000, 200
+    params = get_base_layout_params("cramped_room", L)
+    env = OvercookedMadrona("cramped_room", n, local, debug_compile=False, horizon=L)
+    dev = env.sim.device
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=sds)
+    ego_agent = FusedVectorAgent(nets, n, [(0, n, 0)], seed=11)
+    alt_agent = FusedVectorAgent(nets, n, [(0, n, 1)], seed=12)
+    env.add_partner_agent(alt_agent)
+    rec_actions = torch.zeros((L, 2, n), dtype=torch.int32, device=dev)
+    rec_rew = torch.zeros((L, n), dtype=torch.int32, device=dev)
+    rec_done = torch.zeros((L, n), dtype=torch.int32, device=dev)
+
+    def run_sim(record):
+        obs = env.reset()
+        reward = torch.zeros(n, device=dev)
+        for i in range(L):
+            action = ego_agent.get_action(obs, False)
+            obs, newreward, done, _ = env.step(action)
+            reward += newreward / 20
+            if record:
+                rec_actions[i].copy_(env._actions.view(2, n))
+                rec_rew[i].copy_(newreward)
+                rec_done[i].copy_(done)
+        return reward
+
+    env.sim.reset_all()
+    run_sim(False)                                                   # warm-up episode (ends exactly at the horizon: every kitchen resets)
+    torch.cuda.synchronize()
+    with regions:
+        t0 = time.perf_counter()
+        reward = run_sim(False)
+        torch.cuda.synchronize()
+        ev_s = time.perf_counter() - t0
+    start = env.sim.get_state(0, n)                                  # (the timed episode ended at the horizon too: a fresh episode starts here)
+    reward = run_sim(True)
+    torch.cuda.synchronize()
+    ora = oracle.OracleVecEnv(params, n)
+    ora.set_state(*start)
+    ok = True
+    a_all, r_all, d_all = rec_actions.cpu().numpy(), rec_rew.cpu().numpy(), rec_done.cpu().numpy()
+    total = np.zeros(n)
+    for i in range(L):
+        _, orew, odone = ora.step(np.ascontiguousarray(a_all[i]))
+        ok = ok and np.array_equal(orew[0], r_all[i]) and np.array_equal(np.asarray(odone).astype(bool), d_all[i].astype(bool))
+        total += orew[0] / 20
+    ok = ok and np.allclose(total, reward.cpu().numpy())
+    env.close()
+    ev = {"what": "the reference's evaluation loop (train/testing.py:39-59): cramped_room, 1000 kitchens x 200 steps, two decentralised "
+                  "policies (ego and partner each one FusedVectorAgent launch per step), env.step from Python, reward / 20 accumulated",
+          "kitchens": n, "steps": L, "episode_ms": ev_s * 1e3, "us_per_step": ev_s / L * 1e6, "value": 2 * n * L / ev_s, "unit": "agent-env steps/s",
+          "launches_per_step": 3, "mean_return_over_20": float(reward.mean()), "checked": bool(ok),
+          "checked_note": "a third episode recorded (joint actions, rewards, dones) and replayed through the CPU oracle from the exported start "
+                          "state: rewards and dones bit-identical at every step, the accumulated reward / 20 equal",
+          "note": "launch-bound: 1000 kitchens are 2 MB of planes per step; three small launches and their Python per step"}
+    return drop, ev
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -846,6 +1004,13 @@ def main():
       except Exception as exc:                             # noqa: BLE001
         exchange = {"error": f"{type(exc).__name__}: {exc}"}
 
+    drop_in = eval_1000 = None
+    if world == 1 and not args.no_secondary and not args.no_policy:
+        try:
+            drop_in, eval_1000 = drop_in_and_eval_legs(local, regions, gen)
+        except Exception as exc:                           # noqa: BLE001
+            drop_in = {"error": f"{type(exc).__name__}: {exc}"}
+
     build_info = eng.kernel_build_info
     if rank == 0:
         bytes_per_launch = algorithmic_bytes(S) * n
@@ -926,6 +1091,10 @@ def main():
             out["policy_in_loop"] = policy
         if share is not None:
             out["config4_share_policy_in_loop"] = share
+        if drop_in is not None:
+            out["drop_in_step"] = drop_in
+        if eval_1000 is not None:
+            out["eval_1000"] = eval_1000
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, n)
         out["cold_start"] = {"headline_oc_create_ms": headline_create_ms, "oc_create_ms_8192_kitchens": create_ms,
