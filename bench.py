@@ -463,11 +463,12 @@ def drop_in_and_eval_legs(local, regions, gen):
         with regions:
             kern_us = env.sim.rollout_timed(flat, 500) * 1e3 / 500
         case = {"kitchens": n, "env_kernel_us": kern_us}
-        for name in ("random_partner", "torch_actor_partner"):
+        for name in ("random_partner", "random_partner_graph_step", "torch_actor_partner"):
             tick = [0]
-            agent = RandomVectorAgent(lambda: par[tick[0] % t_act]) if name == "random_partner" else TorchActor(sds[1], dev)
+            agent = TorchActor(sds[1], dev) if name == "torch_actor_partner" else RandomVectorAgent(lambda: par[tick[0] % t_act])
             env.partners[0].clear()
             env.add_partner_agent(agent)
+            env._graph_step = name == "random_partner_graph_step"   # n_step replays a one-launch HIP graph of the env step instead of enqueueing it
             env.reset()
             for t in range(60):
                 tick[0] = t
@@ -491,8 +492,10 @@ def drop_in_and_eval_legs(local, regions, gen):
         env.close()
         drop["cases"].append(case)
     drop["note"] = ("host-bound when host_enqueue_us_per_step ~ us_per_step: the Python of one step (partner call, torch.stack into the "
-                    "persistent [P, N, 1] buffer, one ctypes call, cached ego view) costs more than the kernel; the C-enqueued loops of this "
-                    "line (`value`, policy_in_loop) are what a runner that hands the loop to the library gets")
+                    "persistent [P, N, 1] buffer, one ctypes call, cached ego view) costs more than the kernel; `_graph_step` replays the env "
+                    "launch as a one-kernel HIP graph (OvercookedMadrona(graph_step=True)) -- a graph of one kernel saves nothing, the cost is "
+                    "the Python around it; the C-enqueued loops of this line (`value`, policy_in_loop) are what a runner that hands the loop "
+                    "to the library gets")
 
     # ---- eval_1000: train/testing.py:39-59
     n, L = 1000, 200

@@ -30,7 +30,10 @@ except Exception:                       # pragma: no cover - exercised where gym
 
 class OvercookedMadrona(VectorMultiAgentEnv):
     def __init__(self, layout_name, num_envs, gpu_id, debug_compile=True, use_cpu=False, use_env_cpu=False,
-                 ego_agent_idx=0, horizon=200, num_players=None):
+                 ego_agent_idx=0, horizon=200, num_players=None, graph_step=False):
+        """graph_step (not in the reference's signature; default off): `n_step` replays a one-launch HIP graph of the env step instead
+        of enqueueing the launch through the C ABI each time -- measured, not adopted as the default (bench.py `drop_in_step`: a graph
+        of one kernel costs as much to launch as the kernel; what a Python-driven step pays for is its Python)."""
         if use_cpu:
             raise RuntimeError("use_cpu=True (CPU simulation) is not provided: the MI355X engine has no CPU "
                                "execution mode; the CPU oracle under oracle/ is test infrastructure only")
@@ -55,6 +58,13 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         self.obs_size = self.size * self.channels
         self.state_size = self.obs_size
         self.infos = [{}] * self.num_envs
+        # The simulator owns persistent output buffers and every step overwrites them in place (the reference's data-plane contract,
+        # SURVEY 8(b)): the per-player views handed back by n_step are therefore the same objects every step when the env lives on
+        # the GPU -- built once, not per step (a Python-driven step is host-bound: bench.py `drop_in_step`).
+        self._on_device = env_device == self.sim.device
+        self._views = None
+        self._graph_step = bool(graph_step) and self._on_device
+        self._graph, self._graph_actions_ptr = None, None
 
         self.observation_space = self._setup_observation_space()
         self.share_observation_space = self.observation_space
@@ -68,13 +78,34 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         return a.to(self.device)
 
     def get_obs(self):
+        if self._on_device:
+            if self._views is None:
+                self._views = [VectorObservation(self.static_active, self.static_observations[i], action_mask=self.static_action_mask)
+                               for i in range(self.n_players)]
+            return self._views
         obs = self.to_torch(self.static_observations)
         return [VectorObservation(self.static_active, obs[i], action_mask=self.static_action_mask)
                 for i in range(self.n_players)]
 
     def n_step(self, actions):
-        self.sim.step(actions)
+        if self._graph_step and actions.device == self.sim.device and actions.dtype in (torch.int32, torch.int64) and actions.is_contiguous():
+            if self._graph is None or self._graph_actions_ptr != actions.data_ptr():
+                self._capture_step(actions)
+            self._graph.replay()
+        else:
+            self.sim.step(actions)
+        if self._on_device:
+            return self.get_obs(), self.static_rewards, self.static_dones, self.infos
         return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
+
+    def _capture_step(self, actions):
+        """One-launch HIP graph of sim.step(actions) for this action buffer (VectorMultiAgentEnv stacks into a persistent one)."""
+        self.sim.prepare_kernels()
+        torch.cuda.synchronize(self.sim.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.sim.step(actions)
+        self._graph_actions_ptr = actions.data_ptr()
 
     def n_reset(self):
         # like the reference (envs/overcooked2_env.py:127-128) this re-reads the observation of the
