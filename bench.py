@@ -283,6 +283,56 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
     got = runs[-1][0]
     gather_ms = sum(r[1] for r in runs) / reps
     feat_ms = sum(r[2] for r in runs) / reps
+    # ---- the same update with the exchange CHUNKED and OVERLAPPED with the rollout (ChunkedGather): the rollout's
+    # launches fill the wire buffer chunk by chunk on the current stream; behind each chunk's last step a side stream all-gathers the
+    # chunk's record slots and re-featurises them.  exposed = (rollout with the overlapped exchange) - (the same rollout alone).
+    chunk = max(1, int(os.environ.get("OC_BENCH_EXCHANGE_CHUNK", "25")))
+    n_chunks = (T + chunk - 1) // chunk
+    ex2 = TrajectoryExchange(always_collective=True)
+    out2 = torch.empty_like(out) if not on_host else None
+
+    def rollout_in_chunks(cg):
+        traj.start()
+        for c in range(n_chunks):
+            a0, a1 = c * chunk, min((c + 1) * chunk, T)
+            eng.rollout(acts[a0:a1], a1 - a0, obs=traj.obs[0], reward=traj.reward[a0:a1], done=traj.done[a0:a1], records=traj.records[a0 + 1:a1 + 1])
+            if cg is not None:
+                cg.submit(c)
+        return cg.finish() if cg is not None else None
+
+    exposed_ms = overlap_total_ms = rollout_alone_ms = None
+    chunk_ok = True
+    if not on_host:
+        cg = ex2.chunked(traj, chunk, engine=eng, out=out2)
+        rollout_in_chunks(None)
+        res2 = rollout_in_chunks(cg)                                  # warm-up of both, and the check below
+        torch.cuda.synchronize()
+        chunk_ok = bool(torch.equal(cg.records_all()[rank], traj.records)) and all(
+            torch.equal(res2[k][rank], getattr(traj, k)) for k in ("actions", "reward", "done"))
+        for r in range(world):                                        # (the rollout restarted from the engine's current states: own blocks only)
+            if r == rank:
+                chunk_ok = chunk_ok and _checksum(out2[T, :, r * n:(r + 1) * n]) == _checksum(traj.obs[0])
+        alone, both = [], []
+        for _ in range(reps):
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+            with regions:
+                t0 = time.perf_counter()
+                rollout_in_chunks(None)
+                torch.cuda.synchronize()
+                alone.append(time.perf_counter() - t0)
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+            with regions:
+                t0 = time.perf_counter()
+                rollout_in_chunks(cg)
+                torch.cuda.synchronize()
+                both.append(time.perf_counter() - t0)
+        rollout_alone_ms, overlap_total_ms = min(alone) * 1e3, min(both) * 1e3
+        exposed_ms = max(0.0, overlap_total_ms - rollout_alone_ms)
+        del out2
     # what round 3's path paid on top: one concatenation of the four loose fields into a send buffer (read + write of the shard)
     cat_ms = None
     if not on_host:
@@ -302,17 +352,21 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
     for r in range(world):
         for t in probe_t:
             ok = ok and _checksum(out[t, :, r * n:(r + 1) * n]) == tuple(sums_all[r][t])
-    stats = torch.tensor([gather_ms, feat_ms, 0.0 if ok else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    stats = torch.tensor([gather_ms, feat_ms, 0.0 if (ok and chunk_ok) else 1.0, exposed_ms or 0.0, overlap_total_ms or 0.0, rollout_alone_ms or 0.0],
+                         dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist.is_initialized():
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-    gather_ms, feat_ms, bad = (float(x) for x in stats)
+    gather_ms, feat_ms, bad, exposed_max, overlap_max, alone_max = (float(x) for x in stats)
+    if exposed_ms is not None:
+        exposed_ms, overlap_total_ms, rollout_alone_ms = exposed_max, overlap_max, alone_max
     eng.close()
     del out, recv
     try:
         rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:                                                 # noqa: BLE001
         rccl_version = None
-    update_s = T * c4_step_s + gather_ms / 1e3 + feat_ms / 1e3
+    serial_update_s = T * c4_step_s + gather_ms / 1e3 + feat_ms / 1e3
+    update_s = T * c4_step_s + (exposed_ms / 1e3 if exposed_ms is not None else gather_ms / 1e3 + feat_ms / 1e3)
     return {
         "what": f"BASELINE config 4's per-update exchange: asymmetric_advantages, {total} kitchens in total = {n} per GPU, T = {T} compact "
                 "steps (T+1 state record slots + actions + reward + done: one flat wire buffer the step launches fill in place) through ONE "
@@ -320,6 +374,14 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
         "steps": T, "kitchens_per_gpu": n, "collectives_per_update": 1, "reps": reps,
         "MB_sent_per_gpu": sent_bytes / 1e6, "MB_received_per_gpu": sent_bytes * (world - 1) / 1e6,
         "exchange_ms": gather_ms, "GBps_per_gpu_sent": sent_bytes * max(world - 1, 1) / gather_ms / 1e6,
+        "exposed_ms": exposed_ms,
+        "overlap": {"chunk_steps": chunk, "chunks": n_chunks, "collectives_per_update": n_chunks + 1,
+                    "rollout_alone_ms": rollout_alone_ms, "rollout_with_overlapped_exchange_ms": overlap_total_ms,
+                    "serial_exchange_plus_refeaturize_ms": gather_ms + feat_ms,
+                    "note": "ChunkedGather: behind the last step of every chunk of the rollout a side stream all-gathers the chunk's record "
+                            "slots and re-featurises every peer's block; exposed_ms = what the update waits for beyond the rollout itself "
+                            "(best of the repetitions; at one rank on one GPU both the rollout and the re-featurisation are HBM-bound, so little "
+                            "can hide -- on 8 GPUs the rollout is 8192 kitchens with the policies in the loop, matrix-bound, DESIGN.md 7)"},
         "concatenation_ms_saved": cat_ms,
         "record_step_us": {"one_launch_with_record_destination": one_pass_us, "step_plus_export_states": two_pass_us},
         "model_ms_direct_all_gather": sent_bytes / XGMI_LINK_GBS / 1e6,
@@ -331,8 +393,10 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
         "rccl": {"backend": backend if dist.is_initialized() else None, "world": world, "version": rccl_version,
                  "transport": "device buffers" if not on_host else "host buffers (gloo test hook)", "devices": idents},
         "update_amortised_value": 2 * total * T / update_s, "update_amortised_unit": "agent-env steps/s",
-        "update_amortised_note": f"config 4 over one PPO update: {T} env steps at the config4_split step time + one exchange + the "
-                                 "re-featurisation, whole job",
+        "update_amortised_serial_value": 2 * total * T / serial_update_s,
+        "update_amortised_note": f"config 4 over one PPO update: {T} env steps at the config4_split step time + the EXPOSED part of the chunked, "
+                                 "overlapped exchange and re-featurisation (update_amortised_serial_value: + the whole one-shot exchange and "
+                                 "re-featurisation, rounds 3-5's figure), whole job",
     }
 
 

@@ -14,10 +14,10 @@ from .minibatch import MinibatchSource
 from .rollout import FusedPairedRollout
 from .fused_policy import FusedVectorAgent, PackedNetworks, PolicyPlan
 from .mixed_play import MixedPlayRollout, MixedPlaySchedule
-from .sharding import KitchenShard, Segment, TrajectoryExchange, aligned_threads, local_segments, pairing_segments, segment_critics, segment_policy_indices
+from .sharding import ChunkedGather, KitchenShard, Segment, TrajectoryExchange, aligned_threads, local_segments, pairing_segments, segment_critics, segment_policy_indices
 
 __all__ = [
     "ALIASES", "CLASSIC_LAYOUTS", "get_base_layout_params", "layout_names", "RandomVectorAgent", "VectorAgent",
     "PlayerException", "VectorMultiAgentEnv", "VectorObservation", "OvercookedEngine", "EngineGroup", "GroupPairedRollout", "OvercookedMadrona",
-    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments", "segment_policy_indices", "segment_critics", "aligned_threads",
+    "generate_env", "TrajectoryBuffer", "gae_returns", "normalize_advantages", "gather_rows", "gather_columns", "MinibatchSource", "FusedPairedRollout", "PackedNetworks", "PolicyPlan", "FusedVectorAgent", "MixedPlaySchedule", "MixedPlayRollout", "KitchenShard", "ChunkedGather", "Segment", "TrajectoryExchange", "local_segments", "pairing_segments", "segment_policy_indices", "segment_critics", "aligned_threads",
 ]

@@ -27,6 +27,25 @@
 // oc_policy_kernel (launch_policy decides).  A stretch's blocks go to the wavefronts as pairs, eight blocks per round; what is left
 // (fewer than eight) runs as pairs and -- on the wavefronts that would otherwise idle -- single blocks through the one-block body.
 
+// The interleave of a half-step, pinned for the scheduler: N times [one matrix instruction, then the vector instructions that run
+// under it], an LDS read added from the FIRST_DS-th gap on (masks: 0x008 MFMA, 0x002 VALU, 0x100 LDS read).  The counts are upper
+// bounds -- a group takes what is there -- and the builtin wants literal constants, hence the recursion.
+// f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>), in order: compile-time indices into register arrays
+template <int... Is, class F>
+__device__ __forceinline__ void oc_static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>()), ...); }
+template <int N, class F>
+__device__ __forceinline__ void oc_static_for(F &&f) { oc_static_for_impl(std::make_integer_sequence<int, N>(), static_cast<F &&>(f)); }
+
+template <int N, int FIRST_DS, int I = 0>
+__device__ __forceinline__ void oc_pin_interleave() {
+    if constexpr (I < N) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (I & 3) == 0 ? 5 : 4, 0);
+        if constexpr (I >= FIRST_DS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        oc_pin_interleave<N, FIRST_DS, I + 1>();
+    }
+}
+
 template <int NDIG, bool FC1_LDS>
 __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) {
     // (names and constants the one-block body, included below for single blocks, expects from its kernel)
@@ -44,7 +63,9 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
     long long wg0, wg1, tstart;
     int ti;
     warm_kernarg<false>();
+    stamp(a, wave, lane, 9);
     if (!policy_find_stretch<false>(a, lane, wg0, wg1, ti, tstart)) return;
+    stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     const PolicySlot &S = a.slot[0];
     const int RB = S.RB, P = S.L.P, PH = S.L.PH, H = S.L.H;
@@ -148,9 +169,11 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
     (void)stage;
 
     // rows first (they come from furthest away), then the weights
+    if (loaded_net < 0) stamp(a, wave, lane, 10);
     if (n_items > 0) stage_item(0);
     const bool reload = net != loaded_net;
     if (reload) {
+        if (loaded_net < 0) stamp(a, wave, lane, 11);
         if (loaded_net >= 0) __syncthreads();                         // everybody is done with the previous network
         const uint8_t *blob = S.packed + static_cast<size_t>(net) * S.L.total;
         const int tail_bytes = static_cast<int>(S.L.off_ds + 32 - wstart);
@@ -169,7 +192,9 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
             cbeta = *reinterpret_cast<const v16i *>(blob + S.L.off_conv_sb + 128 + h * 64);
         }
         w1g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(blob + S.L.off_fc1), 0, P * OC_POLICY_FC1_POS_BYTES, 0x00020000);
+        if (loaded_net < 0) stamp(a, wave, lane, 12);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wavefront's share of the weight copy (and its rows) have landed
+        if (loaded_net < 0) stamp(a, wave, lane, 13);
         asm volatile("s_barrier" ::: "memory");
         n_out = min(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(lds_tail + tail_bytes + 16)), kMaxOut);   // header word 4, copied behind the tail
         {
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
             ds3 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(d3));
         }
         loaded_net = net;
+        stamp(a, wave, lane, 1);
     }
 
     for (int item = 0; item < n_items; ++item) {
@@ -199,4 +225,5 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
 #include "policy_duo_body.h"
     }
   }
+    stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }

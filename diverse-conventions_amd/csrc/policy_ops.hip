@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "overcooked_ops.h"
@@ -895,6 +896,8 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const P
     stamp(a, wave, lane, 8); stamp(a, wave, lane, 15);
 }
 
+#include "policy_duo_kernel.h"
+
 // The three dense layers' power-of-two exponents (their largest |weight| into [2^13, 2^14), policy_pack.h) -> the image's descale
 // section: one workgroup, first in the stream; the pack kernel below reads the exponents from there.
 __global__ void oc_policy_scales_kernel(oc_policy_layout L, oc_policy_weights w, uint32_t *dst) {
@@ -1309,19 +1312,42 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
 #ifdef OC_DIAGNOSTICS
     if (fold && !wave_tiles && !multi && !gather) kernel = kernels_fold[fc1_lds ? 1 : 0][conv_lds ? 1 : 0];
 #endif
+    // Round 6: TWO blocks per wavefront (policy_duo_kernel.h) wherever eight row-staging areas fit next to the dense tail -- one
+    // wavefront per SIMD interleaving two independent blocks, conv digits in registers, fc1 LDS-resident if that fits as well.  Plain
+    // single-grid launches only: gather tiles, select codes, several grids, wave tiles and the diagnostics' fold / forced plans stay
+    // on oc_policy_kernel.  OC_POLICY_DUO=0 (read per call) keeps every launch there, for A/B runs and plan-equality checks.
+    bool duo = !multi && !wave_tiles && !gather && !fold && !s0.row_select && !(env_plan && env_plan[0]);
+    if (duo) { const char *v = getenv("OC_POLICY_DUO"); if (v && v[0] == '0') duo = false; }
+    bool duo_fc1 = false;
+    if (duo) {
+        duo_fc1 = kb(w_tail_all + 32) + 8 * obs1 <= kLds;
+        if (kb((duo_fc1 ? w_tail_all : w_tail_small) + 32) + 8 * obs1 > kLds) duo = false;
+    }
+    size_t lds_duo = 0;
+    if (duo) {
+        static const kernel_t kernels_duo[4][2] = {{oc_policy_duo_kernel<1, false>, oc_policy_duo_kernel<1, true>}, {oc_policy_duo_kernel<2, false>, oc_policy_duo_kernel<2, true>},
+                                                   {oc_policy_duo_kernel<3, false>, oc_policy_duo_kernel<3, true>}, {oc_policy_duo_kernel<4, false>, oc_policy_duo_kernel<4, true>}};
+        kernel = kernels_duo[digits - 1][duo_fc1 ? 1 : 0];
+        waves = 4;
+        fc1_lds = duo_fc1;
+        conv_lds = false;
+        a.lds_weight_bytes = static_cast<int>(kb((duo_fc1 ? w_tail_all : w_tail_small) + 32));
+        lds_duo = static_cast<size_t>(a.lds_weight_bytes) + 8u * static_cast<size_t>(a.lds_wave_bytes);
+    }
     // the GPU that owns the buffers, not whatever device happens to be current: its CU count, its LDS opt-in, its stream
     int dev = oc_device_of_pointer(s0.packed);
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: no current device");
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2][5] = {};                   // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][wave_tiles ? 2 : multi ? 1 : gather ? 3 : fold ? 4 : 0];
-    if (lds > 64 * 1024 && lds > granted) {
+    static size_t lds_granted[64][4][2][2][6] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][duo ? 5 : wave_tiles ? 2 : multi ? 1 : gather ? 3 : fold ? 4 : 0];
+    const size_t lds_use = duo ? lds_duo : lds;
+    if (lds_use > 64 * 1024 && lds_use > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 static_cast<int>(lds));
-        if (e != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
-        granted = lds;
+                                                 static_cast<int>(lds_use));
+        if (e != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: %zu bytes of LDS refused: %s", lds_use, hipGetErrorString(e));
+        granted = lds_use;
     }
     // one workgroup per CU; each takes an equal share of the 32-row blocks (workgroups without a share return at once)
     static int cus_of[64] = {};
@@ -1345,7 +1371,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
     static const char *const env_grid = OC_DIAG_ENV("OC_POLICY_GRID");
     if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(64 * waves), lds_use, stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: launch failed: %s", hipGetErrorString(err));
     return OC_OK;

@@ -26,6 +26,7 @@ LIB_PATH = LIB_OVERRIDE or os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE el
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
 HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h"), os.path.join(CSRC, "policy_block_body.h"),
+           os.path.join(CSRC, "policy_duo_kernel.h"), os.path.join(CSRC, "policy_duo_body.h"),
            os.path.join(CSRC, "oc_np_kernels.h")]
 KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")              # ahead-of-time (generic) build
 KERNEL_COMMON = os.path.join(CSRC, "oc_step_common.h")              # the two headers hiprtc compiles per engine / group

@@ -132,6 +132,10 @@ class TrajectoryExchange:
             res[name] = got[:, off:off + n].view((got.shape[0],) + shape)
         return res
 
+    def chunked(self, traj, chunk_steps, engine=None, out=None, recv=None, stream=None):
+        """The same exchange in chunks of `chunk_steps` steps on a side stream, overlapped with the rollout: see ChunkedGather."""
+        return ChunkedGather(self, traj, chunk_steps, engine=engine, out=out, recv=recv, stream=stream)
+
     def gather_trajectory(self, records, actions, reward, done):
         """Loose fields (one concatenation pass; prefer gather_buffer): records int32 [T, n, rec/4]; actions int32 [T, P, n];
         reward int32 [T, n]; done int32 [T, n] -> dict of [world, ...] views of ONE gathered buffer (peer r's shard at index r)."""
@@ -169,6 +173,117 @@ class TrajectoryExchange:
         for r in range(world):
             engine.encode_trajectory_into(records_all[r], out, r * n)
         return out
+
+
+class ChunkedGather:
+    """The per-update exchange cut into chunks of `chunk_steps` time steps and OVERLAPPED with the rollout that is still filling the
+    wire buffer (consumer: the reference's XP / MP losses read whole buffers once per update, train/XD/xd.py:311-397,
+    so nothing needs a peer's step before the update starts -- and nothing stops it from travelling earlier).
+
+    The step launches write the records of step t into slot t + 1 of the wire buffer as they run.  After the last step of chunk c has
+    been enqueued the caller says `submit(c)`: an event is recorded on the current (rollout) stream, and on a SIDE stream -- behind
+    that event -- the chunk's record slots go through one `all_gather_into_tensor` (RCCL over xGMI; the slots of a chunk are one
+    contiguous range of the wire buffer) and, when an engine and an output tensor were given, every peer's block of the chunk is
+    re-featurised into the chunk's time slots of the global observation tensor (`oc_encode_trajectory`, one launch per peer).  The
+    rollout stream never waits.  `finish()` sends the small fields -- actions | reward | done, the contiguous tail of the wire buffer,
+    20 bytes per kitchen-step against the records' 4 S + 16 -- in one more collective and makes the current stream wait for the side
+    stream.  Collectives per update: chunks + 1.
+
+    Receive layout: chunk-major -- chunk c's gathered block is `[world, slots_c, n, rec/4]` (peers in rank order), all chunks in one
+    flat buffer; `records_all()` assembles the one-shot layout `[world, T + 1, n, rec/4]` of `gather_buffer` for consumers that want
+    it (a copy: tests compare it bit for bit with the one-shot gather).  On the CPU (gloo: the tests) everything runs in line."""
+
+    def __init__(self, exchange, traj, chunk_steps, engine=None, out=None, recv=None, stream=None):
+        from .trajectory import wire_layout
+        if traj.wire is None:
+            raise ValueError("ChunkedGather needs a TrajectoryBuffer(store_states=True): its fields live in one wire buffer")
+        self.ex, self.traj, self.engine, self.out = exchange, traj, engine, out
+        self.T, self.C = int(traj.T), max(1, int(chunk_steps))
+        self.n = traj.engine.num_kitchens
+        self.recw = traj.engine.record_bytes // 4
+        self.fields, words = wire_layout(self.T, traj.P, self.n, self.recw)
+        assert words == traj.wire.numel()
+        self.n_chunks = (self.T + self.C - 1) // self.C
+        world = exchange.world
+        # record slots of chunk c: [s0, s1) -- chunk 0 also carries slot 0 (the state the trajectory starts from)
+        self.slots = [(0 if c == 0 else c * self.C + 1, min((c + 1) * self.C, self.T) + 1) for c in range(self.n_chunks)]
+        slot_words = self.n * self.recw
+        need = world * (self.T + 1) * slot_words
+        dev = traj.wire.device
+        if recv is None:
+            recv = torch.empty(need, dtype=torch.int32, device=dev)
+        elif recv.numel() < need or recv.dtype != torch.int32 or not recv.is_contiguous():
+            raise ValueError(f"recv must be a contiguous int32 buffer of at least {need} words")
+        self.recv = recv
+        self.chunk_views = []
+        for s0, s1 in self.slots:
+            off = world * s0 * slot_words
+            self.chunk_views.append(recv[off:off + world * (s1 - s0) * slot_words].view(world, s1 - s0, self.n, self.recw))
+        self.small = None
+        self.cuda = dev.type == "cuda"
+        self.stream = (stream if stream is not None else torch.cuda.Stream(dev)) if self.cuda else None
+        self.events = [torch.cuda.Event() for _ in range(self.n_chunks)] if self.cuda else None
+        self.submitted = 0
+
+    def chunk_of_step(self, t):
+        """chunk that the step writing record slot t + 1 belongs to"""
+        return min(t // self.C, self.n_chunks - 1)
+
+    def last_step_of(self, c):
+        return min((c + 1) * self.C, self.T) - 1
+
+    def _side(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.cuda else contextlib.nullcontext()
+
+    def submit(self, c):
+        """Call after the last step of chunk c has been enqueued on the current stream (chunks in order)."""
+        if c != self.submitted:
+            raise ValueError(f"chunks are submitted in order: expected {self.submitted}, got {c}")
+        s0, s1 = self.slots[c]
+        off, slot_words = self.fields["records"][0], self.n * self.recw
+        send = self.traj.wire[off + s0 * slot_words: off + s1 * slot_words]
+        if self.cuda:
+            self.events[c].record(torch.cuda.current_stream(send.device))
+        with self._side():
+            if self.cuda:
+                self.stream.wait_event(self.events[c])
+            got = self.ex.all_gather(send, out=self.chunk_views[c].view(-1))
+            if got.data_ptr() != self.chunk_views[c].data_ptr():          # (one rank without always_collective: all_gather hands the shard back)
+                self.chunk_views[c].view(-1).copy_(got.reshape(-1))
+            if self.engine is not None and self.out is not None:
+                for r in range(self.ex.world):
+                    self.engine.encode_trajectory_into(self.chunk_views[c][r], self.out[s0:s1], r * self.n)
+        self.submitted = c + 1
+
+    def finish(self):
+        """The small fields in one more collective; the current stream then waits for everything the side stream did.
+        -> {"records": [per-chunk [world, slots, n, rec/4] views], "actions" / "reward": [world, T, P, n], "done": [world, T, n]}"""
+        if self.submitted != self.n_chunks:
+            raise ValueError(f"{self.n_chunks - self.submitted} chunk(s) were never submitted")
+        a0 = self.fields["actions"][0]
+        send = self.traj.wire[a0:]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(send.device))
+        with self._side():
+            if self.cuda:
+                self.stream.wait_event(ev)
+            self.small = self.ex.all_gather(send)                           # [world, words of actions | reward | done]
+        if self.cuda:
+            torch.cuda.current_stream(send.device).wait_stream(self.stream)
+        res = {"records": self.chunk_views}
+        for name in ("actions", "reward", "done"):
+            off, shape = self.fields[name]
+            cnt = 1
+            for d in shape:
+                cnt *= d
+            res[name] = self.small[:, off - a0:off - a0 + cnt].view((self.small.shape[0],) + shape)
+        return res
+
+    def records_all(self):
+        """[world, T + 1, n, rec/4] in the one-shot layout (a copy)."""
+        return torch.cat(self.chunk_views, dim=1)
 
 
 def segment_scores(episode_returns: torch.Tensor, segments: List[Segment], group: Optional[dist.ProcessGroup] = None):

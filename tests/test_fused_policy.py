@@ -321,6 +321,7 @@ def test_cooperative_blocks(W, H, blocks, monkeypatch):
     wavefront (OC_POLICY_COOP=0): equal to f32 rounding -- and NOT bit for bit, which shows the shared path ran; deterministic actions
     agree wherever the two best log-probabilities are further apart than that rounding.  Ragged last block, actors and critics."""
     from oracle.policy_oracle import log_softmax, reference_forward
+    monkeypatch.setenv("OC_POLICY_DUO", "0")                        # (grids of up to 25 tiles otherwise run two blocks per wavefront: no shared blocks there)
     rng = np.random.default_rng(W * 1000 + H * 10 + blocks)
     wgs = 128                                                       # (a table of at least half as many tiles as CUs maps tile i to workgroup i)
     n = wgs * blocks * 32 - 7                                       # every workgroup a stretch of `blocks` blocks, the very last one ragged
@@ -352,6 +353,42 @@ def test_cooperative_blocks(W, H, blocks, monkeypatch):
     full = np.concatenate([np.arange(w * rows_wg, w * rows_wg + (blocks - blocks % 4) * 32) for w in range(wgs)])
     full = full[full < n]
     assert np.array_equal(a1["logp"][full], a0["logp"][full]) and np.array_equal(v1[full], v0[full])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(5, 4), (5, 5), (3, 3)])
+def test_two_blocks_per_wavefront_equal_the_one_block_kernel(W, H, monkeypatch):
+    """oc_policy_duo_kernel (round 6: one wavefront per SIMD interleaving TWO 32-row blocks, policy_duo_kernel.h / policy_duo_body.h)
+    against oc_policy_kernel (OC_POLICY_DUO=0) on the same launches: BIT for bit -- the arithmetic and the order of every accumulation
+    are the same, only the instruction order differs -- for every way a stretch of 1 .. 19 blocks falls onto the four wavefronts
+    (rounds of pairs, a tail of pairs and / or single blocks, ragged last block), actors (sampled and deterministic) and critics, and
+    against the numpy restatement of the reference's f32 forward."""
+    from oracle.policy_oracle import log_softmax, reference_forward
+    monkeypatch.setenv("OC_POLICY_COOP", "0")                       # (the one-block kernel's cooperative blocks sum their fc1 partials in another order)
+    actor, critic = random_net(W, H, 6, ACTOR_HEAD, 21), random_net(W, H, 1, CRITIC_HEAD, 22)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[actor], critics=[critic])
+    wgs = 128
+    for blocks in list(range(1, 12)) + [16, 17, 19]:
+        rng = np.random.default_rng(W * 100 + H * 10 + blocks)
+        n = wgs * blocks * 32 - 13
+        obs_np = (rng.random((n, W, H, 20)) < 0.15).astype(np.int8) * rng.integers(1, 21, size=(n, W, H, 20), dtype=np.int8)
+        obs = torch.from_numpy(obs_np).cuda()
+        got = {}
+        for duo in ("1", "0"):
+            monkeypatch.setenv("OC_POLICY_DUO", duo)
+            a = _run(nets, n, [(0, n, 0, TILE_ACT)], obs, rows_per_tile=blocks * 32, deterministic=True)
+            smp = _run(nets, n, [(0, n, 0, TILE_ACT)], obs, rows_per_tile=blocks * 32, deterministic=False, seed=5, counter=blocks)
+            v = _run(nets, n, [(0, n, 1, 0)], obs, rows_per_tile=blocks * 32)["raw"].reshape(-1)[:n]
+            got[duo] = (a, smp, v)
+        (a1, s1, v1), (a0, s0, v0) = got["1"], got["0"]
+        assert np.array_equal(a1["logp"], a0["logp"]) and np.array_equal(a1["actions"], a0["actions"]) and np.array_equal(a1["action_logp"], a0["action_logp"]), blocks
+        assert np.array_equal(s1["actions"], s0["actions"]) and np.array_equal(s1["action_logp"], s0["action_logp"]), blocks
+        assert np.array_equal(v1, v0), blocks
+        if blocks in (1, 5, 17):
+            want_lp = log_softmax(reference_forward(actor, obs_np, ACTOR_HEAD))
+            want_v = reference_forward(critic, obs_np, CRITIC_HEAD).reshape(-1)
+            scale = max(1.0, float(np.abs(want_lp).max()), float(np.abs(want_v).max()))
+            assert np.abs(a1["logp"] - want_lp).max() < 4e-6 * scale and np.abs(v1 - want_v).max() < 4e-6 * scale, blocks
 
 
 @pytest.mark.gpu
