@@ -902,6 +902,37 @@ def main():
                                               "the dense layers; 10 368 with three bf16 pieces in round 3, 11 520 in round 2, 23 040 with f32 MFMAs in round 1); the VALU "
                                               "work between the layers does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
           eng2.close()
+          # the same rollout with the kitchens per pairing segment a multiple of 32 (aligned_threads: what INTEGRATION.md recommends --
+          # the policy kernel evaluates 32 rows per block): 15 x 4352 kitchens.  Every workgroup's stretch is then whole rounds of
+          # eight blocks, or leaves five or more over, and the launch runs TWO blocks per wavefront (oc_policy_duo_kernel, round 6)
+          from diverse_conventions_amd import aligned_threads
+          th_a = aligned_threads(n, k)
+          eng2a = OvercookedEngine(params, th_a * (2 * k + 1), local)
+          ro_a = FusedPairedRollout(eng2a, nets, th_a, k)
+          ro_a.step(SEC_WARMUP)
+          torch.cuda.synchronize()
+          with regions:
+              pe0.record()
+              for _ in range(psteps):
+                  ro_a.plan.forward(eng2a.obs, actions=ro_a.actions, action_logp=ro_a.logp, seed=0, counter=0, device_counter=ro_a.draw)
+              pe1.record()
+              torch.cuda.synchronize()
+          pol_a_us = pe0.elapsed_time(pe1) * 1e3 / psteps
+          step_a_us = float("inf")
+          for _ in range(2):
+              with regions:
+                  t1 = time.perf_counter()
+                  ro_a.step(psteps)
+                  torch.cuda.synchronize()
+                  step_a_us = min(step_a_us, (time.perf_counter() - t1) / psteps * 1e6)
+          rows_a = 2 * eng2a.num_kitchens
+          policy["aligned_segments"] = {
+              "what": f"the same rollout at aligned_threads({n}, {k}) = {th_a} kitchens per pairing segment ({eng2a.num_kitchens} kitchens): segments of whole "
+                      "32-row blocks; the policy launch runs two blocks per wavefront (oc_policy_duo_kernel)",
+              "kitchens": eng2a.num_kitchens, "us_per_step": step_a_us, "value": 2 * eng2a.num_kitchens / step_a_us * 1e6, "unit": "agent-env steps/s",
+              "policy_kernel_us_per_launch": pol_a_us, "network_evaluations": rows_a,
+              "policy_kernel_frac_of_issue_bound": bound_us * rows_a / rows / pol_a_us, "checked": check_policy_in_loop(ro_a, eng2a, params)}
+          eng2a.close()
       except Exception as exc:                             # noqa: BLE001
         policy = {"error": f"{type(exc).__name__}: {exc}"}
 

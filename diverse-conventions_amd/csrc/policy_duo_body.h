@@ -2,6 +2,9 @@
 // inside the kernel's item loop (no include guard; everything it names is a local of the kernel).  Arithmetic and the order of every
 // accumulation are those of policy_block_body.h: a block's outputs do not depend on whether it ran alone or as half of a pair.
         {
+#ifndef OC_DUO_ABLATE
+#define OC_DUO_ABLATE 0      /* timing experiments only (tools/ab_duo_ablate.sh): 1 no operand conversion in the position loop, 2 fc1 fragments loaded once, 4 no B-fragment reads in the loop, 8 no conv MFMAs, 16 no fc1 MFMAs -- outputs are then wrong */
+#endif
         typedef std::integral_constant<int, 0> BlkA;
         typedef std::integral_constant<int, 1> BlkB;
         // (diagnostics build: phase stamps of this wavefront's first pair of the launch -- coarse -- and of its second -- fine; the slots of
@@ -17,7 +20,12 @@
         if (traced) stamp(a, wave, lane, 3);
         if (traced2) stamp(a, wave, lane, 17);
         const uint8_t *const rp[2] = {ldsw + col * RB + 16 * h, ldsw2 + col * RB + 16 * h};
-        int pq[2] = {0, 0}, xq[2] = {0, 0}, yq[2] = {0, 0};           // position whose B operands bfr[b] holds (wave-uniform: scalar registers)
+        // Byte offset (inside a staged row) of the conv position whose B operands a block reads next.  A build for ONE grid (GW > 0:
+        // the kernel's template arguments) knows every offset at compile time -- the position loop is unrolled, the LDS reads take
+        // immediate offsets off one base register and nothing scalar is left in the loop; the generic build (GW == 0) walks counters.
+        constexpr bool kStaticGrid = GW > 0;
+        constexpr int kSPH = kStaticGrid ? GH - 2 : 1, kSP = kStaticGrid ? (GW - 2) * (GH - 2) : 1, kSColstep = GH * OC_POLICY_C;
+        int pq[2] = {0, 0}, xq[2] = {0, 0}, yq[2] = {0, 0};           // generic build: position whose B operands bfr[b] holds (wave-uniform: scalar registers)
         v4i bfr[2][6];
         v16i acc[2][NDIG];
         v16f h1[2][2];
@@ -36,36 +44,51 @@
             constexpr int b = decltype(Bc)::value;
             read_bfrags(rp[b], (xq[b] * H + yq[b]) * OC_POLICY_C, colstep, bfr[b]);
         };
-        // A block's operand conversion as 32 quarter-steps of four vector instructions each (pair j = accumulator registers 2j, 2j + 1;
-        // quarter q: 0 top digits combined + converted, 1 low digit converted + scaled, 2 fma + relu / clamp, 3 the f16 split), so that a
-        // half-step can deal them out between the other block's MFMAs.  The values in flight between quarters live in cvt_t / cvt_u.
-        float cvt_t[2][2], cvt_u[2][2];
-        auto convert_q = [&](auto Bc, auto Sc) {
-            constexpr int b = decltype(Bc)::value, s = decltype(Sc)::value, j = s >> 2, q = s & 3, r = 2 * j;
+        // static grid: offset of position min(p, P - 1) (clamped: the last is re-read)
+        auto static_off = [](int p) constexpr { const int q = p < kSP - 1 ? p : kSP - 1; return ((q / kSPH) * GH + q % kSPH) * OC_POLICY_C; };
+        (void)static_off;
+        // A block's operand conversion as 128 single-instruction micro-steps (NDIG = 3; pair j = accumulator registers 2j, 2j + 1 goes
+        // through 16 instructions: top digits combined x2, converted x2, low digit converted x2, scaled x2, fma x2, relu / clamp x2, f16
+        // hi, remainder x2, f16 lo), dealt out behind the other block's MFMAs FOUR OR FIVE to a gap: five independent single-issue
+        // instructions are what hides under a 32-cycle MFMA and the sixth costs ~22 cycles (tools/probes/mfma_valu_overlap.hip), and a
+        // dependent instruction right behind its producer waits for it -- so four pairs advance together, stage by stage: micro-step
+        // u = 64 g + 4 k + i is stage k of pair 4 g + i, and the instructions of one gap belong to four different pairs.
+        float cv_t[2][8][2], cv_u[2][8][2];
+        v2h cv_h[2][8];
+        auto convert_u = [&](auto Bc, auto Uc) {
+            constexpr int b = decltype(Bc)::value, u = decltype(Uc)::value;
             constexpr int kB = OC_POLICY_DIGIT_BASE;
             const float sc = oc_pow2f(-oc_policy_conv_shift(NDIG));
             if constexpr (NDIG == 3) {
-                if constexpr (q == 0) {
-                    cvt_t[b][0] = static_cast<float>(acc[b][0][r] * kB + acc[b][1][r]); cvt_t[b][1] = static_cast<float>(acc[b][0][r + 1] * kB + acc[b][1][r + 1]);
-                } else if constexpr (q == 1) {
-                    cvt_u[b][0] = static_cast<float>(acc[b][2][r]) * sc; cvt_u[b][1] = static_cast<float>(acc[b][2][r + 1]) * sc;
-                } else if constexpr (q == 2) {
-                    cvt_t[b][0] = relu_clamp(__builtin_fmaf(cvt_t[b][0], kB * sc, cvt_u[b][0])); cvt_t[b][1] = relu_clamp(__builtin_fmaf(cvt_t[b][1], kB * sc, cvt_u[b][1]));
-                } else {
-                    int hi, lo;
-                    split_pair(cvt_t[b][0], cvt_t[b][1], hi, lo);
-                    xb[b][0][j >> 2][j & 3] = hi; xb[b][1][j >> 2][j & 3] = lo;
+                constexpr int g = u >> 6, k = (u & 63) >> 2, j = 4 * g + (u & 3), r = 2 * j, e = k & 1;
+                if constexpr (k < 2) cv_t[b][j][e] = __builtin_bit_cast(float, acc[b][0][r + e] * kB + acc[b][1][r + e]);            // v_lshl_add_u32 (the integer, for now)
+                else if constexpr (k < 4) cv_t[b][j][e] = static_cast<float>(__builtin_bit_cast(int, cv_t[b][j][e]));                 // v_cvt_f32_i32
+                else if constexpr (k < 6) cv_u[b][j][e] = static_cast<float>(acc[b][2][r + e]);                                      // v_cvt_f32_i32
+                else if constexpr (k < 8) cv_u[b][j][e] = cv_u[b][j][e] * sc;                                                        // v_mul_f32
+                else if constexpr (k < 10) cv_t[b][j][e] = __builtin_fmaf(cv_t[b][j][e], kB * sc, cv_u[b][j][e]);                    // v_fmac_f32
+                else if constexpr (k < 12) cv_t[b][j][e] = relu_clamp(cv_t[b][j][e]);                                                // v_med3_f32
+                else if constexpr (k == 12) {                                                                                        // v_cvt_pk_f16_f32: the hi pieces
+                    cv_h[b][j] = __builtin_convertvector(v2f{cv_t[b][j][0], cv_t[b][j][1]}, v2h);
+                    xb[b][0][j >> 2][j & 3] = __builtin_bit_cast(int, cv_h[b][j]);
+                } else if constexpr (k == 13) {                                                                                      // v_fma_mix_f32: x - hi, exact
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(cv_u[b][j][0]) : "v"(cv_h[b][j]), "v"(cv_t[b][j][0]));
+                } else if constexpr (k == 14) {
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(cv_u[b][j][1]) : "v"(cv_h[b][j]), "v"(cv_t[b][j][1]));
+                } else {                                                                                                             // v_cvt_pk_f16_f32: the lo pieces
+                    xb[b][1][j >> 2][j & 3] = __builtin_bit_cast(int, __builtin_convertvector(v2f{cv_u[b][j][0], cv_u[b][j][1]}, v2h));
                 }
-            } else {                                                  // other digit counts: the whole pair in its last quarter (same arithmetic: combine_pair)
-                if constexpr (q == 3) {
+            } else {                                                  // other digit counts: whole pairs (combine_pair: the same arithmetic), one per 16 micro-steps
+                if constexpr ((u & 15) == 15) {
+                    constexpr int j = u >> 4;
                     int hi, lo;
                     float x0, x1;
-                    combine_pair(acc[b], r, x0, x1);
+                    combine_pair(acc[b], 2 * j, x0, x1);
                     split_pair(x0, x1, hi, lo);
                     xb[b][0][j >> 2][j & 3] = hi; xb[b][1][j >> 2][j & 3] = lo;
                 }
             }
         };
+        constexpr int kCvtSteps = 128;
         auto load_w1 = [&](int p) {
 #pragma unroll
             for (int q = 0; q < kPieces; ++q)
@@ -95,9 +118,11 @@
             h1[b][m] = mfma_f16(w1r[kTermW[t]][g][m], xb[b][kTermX[t]][g], h1[b][m]);
         };
         // one sixth of a block's B fragments (kernel column kx, half s) of the position its counters point at
-        auto read_b_i = [&](auto Bc, auto Kc) {
+        auto read_b_i = [&](auto Bc, auto Kc, auto Pc) {              // Pc: the position (static grid; ignored by the generic build)
             constexpr int b = decltype(Bc)::value, k = decltype(Kc)::value;
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(rp[b] + (xq[b] * H + yq[b]) * OC_POLICY_C + (k >> 1) * colstep + 32 * (k & 1));
+            const uint32_t *q;
+            if constexpr (kStaticGrid) q = reinterpret_cast<const uint32_t *>(rp[b] + (static_off(decltype(Pc)::value) + (k >> 1) * kSColstep + 32 * (k & 1)));
+            else q = reinterpret_cast<const uint32_t *>(rp[b] + (xq[b] * H + yq[b]) * OC_POLICY_C + (k >> 1) * colstep + 32 * (k & 1));
             v4i v;
             v.x = static_cast<int>(q[0]); v.y = static_cast<int>(q[1]); v.z = static_cast<int>(q[2]); v.w = static_cast<int>(q[3]);
             bfr[b][k] = v;
@@ -106,18 +131,19 @@
         // A half-step: block X's MFMAs (its conv of the next position unless this is the last, then its fc1 of the current one), block Y's
         // conversion quarters dealt out behind them, X's next B fragments behind its conv.  Every MFMA with what runs under it is a
         // scheduling region of its own (sched_barrier): the order below IS the instruction order.
-        auto half_step = [&](auto Xc, auto Yc, auto last_tag) {
+        auto half_step = [&](auto Xc, auto Yc, auto last_tag, auto Pc) {   // Pc (static grid): the position whose B fragments X reads during this half-step
             constexpr bool kLast = decltype(last_tag)::value;
             constexpr int nM = (kLast ? 0 : kConvM) + kFc1M;
-            if constexpr (!kLast) advance(Xc);                        // (X's counters: the position whose fragments are read during this half-step)
+            if constexpr (!kLast && !kStaticGrid) advance(Xc);        // (X's counters: the position whose fragments are read during this half-step)
             oc_static_for<nM>([&](auto Ic) {
                 constexpr int i = decltype(Ic)::value;
-                if constexpr (!kLast && i < kConvM) conv_i(Xc, Ic);
-                else fc1_i(Xc, std::integral_constant<int, i - (kLast ? 0 : kConvM)>());
+                if constexpr (!kLast && i < kConvM) { if constexpr (!(OC_DUO_ABLATE & 8)) conv_i(Xc, Ic); }
+                else { if constexpr (!(OC_DUO_ABLATE & 16)) fc1_i(Xc, std::integral_constant<int, i - (kLast ? 0 : kConvM)>()); }
                 // quarters [32 i / nM, 32 (i + 1) / nM) of Y's conversion
-                oc_static_for<(32 * (i + 1)) / nM - (32 * i) / nM>([&](auto Sc) { convert_q(Yc, std::integral_constant<int, (32 * i) / nM + decltype(Sc)::value>()); });
+                if constexpr (!(OC_DUO_ABLATE & 1) || kLast)
+                    oc_static_for<(kCvtSteps * (i + 1)) / nM - (kCvtSteps * i) / nM>([&](auto Sc) { convert_u(Yc, std::integral_constant<int, (kCvtSteps * i) / nM + decltype(Sc)::value>()); });
                 // X's B fragments of the position after next: one sixth behind every second fc1 MFMA (their registers are free: X's conv has issued)
-                if constexpr (!kLast && i >= kConvM && ((i - kConvM) & 1) == 0 && (i - kConvM) / 2 < 6) read_b_i(Xc, std::integral_constant<int, (i - kConvM) / 2>());
+                if constexpr (!(OC_DUO_ABLATE & 4) && !kLast && i >= kConvM && ((i - kConvM) & 1) == 0 && (i - kConvM) / 2 < 6) read_b_i(Xc, std::integral_constant<int, (i - kConvM) / 2>(), Pc);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -133,32 +159,49 @@
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h1[b][m][r] = bq[m * 8 + (r >> 2)][r & 3];
         }
-        read_b(BlkA());
-        read_b(BlkB());
+        typedef std::integral_constant<int, 0> Pos0;
+        typedef std::integral_constant<int, 1> Pos1;
+        auto read_b_all = [&](auto Bc, auto Pc) {
+            if constexpr (kStaticGrid) oc_static_for<6>([&](auto Kc) { read_b_i(Bc, Kc, Pc); });
+            else read_b(Bc);
+        };
+        read_b_all(BlkA(), Pos0());
+        read_b_all(BlkB(), Pos0());
         load_w1(0);
         oc_static_for<kConvM>([&](auto Ic) { conv_i(BlkA(), Ic); });  // A.conv(0)
-        advance(BlkA());
-        read_b(BlkA());                                               // A: position 1
+        if constexpr (!kStaticGrid) advance(BlkA());
+        read_b_all(BlkA(), Pos1());                                   // A: position 1
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 18);
         oc_static_for<kConvM>([&](auto Ic) {                          // B.conv(0) beside A.convert(0)
             constexpr int i = decltype(Ic)::value;
             conv_i(BlkB(), Ic);
-            oc_static_for<(32 * (i + 1)) / kConvM - (32 * i) / kConvM>([&](auto Sc) { convert_q(BlkA(), std::integral_constant<int, (32 * i) / kConvM + decltype(Sc)::value>()); });
+            oc_static_for<(kCvtSteps * (i + 1)) / kConvM - (kCvtSteps * i) / kConvM>([&](auto Sc) { convert_u(BlkA(), std::integral_constant<int, (kCvtSteps * i) / kConvM + decltype(Sc)::value>()); });
             __builtin_amdgcn_sched_barrier(0);
         });
-        advance(BlkB());
-        read_b(BlkB());                                               // B: position 1
+        if constexpr (!kStaticGrid) advance(BlkB());
+        read_b_all(BlkB(), Pos1());                                   // B: position 1
         __builtin_amdgcn_sched_barrier(0);
         if (traced2) stamp(a, wave, lane, 19);
 
         // ---- the position loop: per position two half-steps, each the MFMAs of one block beside the other block's operand conversion
-        for (int p = 0; p + 1 < P; ++p) {
-            half_step(BlkA(), BlkB(), NotLast());                     // A.conv(p+1), A.fc1(p)  ||  B.convert(p)
-            half_step(BlkB(), BlkA(), NotLast());                     // B.conv(p+1), B.fc1(p)  ||  A.convert(p+1)
-            load_w1(p + 1);                                           // the next position's fc1 fragments: requested behind B's fc1, used behind A's next conv
-            __builtin_amdgcn_sched_barrier(0);
-            if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
+        if constexpr (kStaticGrid) {
+            oc_static_for<kSP - 1>([&](auto Pc) {
+                constexpr int p = decltype(Pc)::value;
+                half_step(BlkA(), BlkB(), NotLast(), std::integral_constant<int, p + 2>());     // A.conv(p+1), A.fc1(p)  ||  B.convert(p)
+                half_step(BlkB(), BlkA(), NotLast(), std::integral_constant<int, p + 2>());     // B.conv(p+1), B.fc1(p)  ||  A.convert(p+1)
+                if (!(OC_DUO_ABLATE & 2)) load_w1(p + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
+            });
+        } else {
+            for (int p = 0; p + 1 < P; ++p) {
+                half_step(BlkA(), BlkB(), NotLast(), Pos0());         // A.conv(p+1), A.fc1(p)  ||  B.convert(p)
+                half_step(BlkB(), BlkA(), NotLast(), Pos0());         // B.conv(p+1), B.fc1(p)  ||  A.convert(p+1)
+                if (!(OC_DUO_ABLATE & 2)) load_w1(p + 1);             // the next position's fc1 fragments: requested behind B's fc1, used behind A's next conv
+                __builtin_amdgcn_sched_barrier(0);
+                if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
+            }
         }
 
         // ---- the dense tail, interleaved the same way.  A layer input of a block (four k-groups of eight registers) becomes operand pieces
@@ -188,7 +231,7 @@
             });
         };
         // last position: A.fc1(P-1) || B.convert(P-1);  B.fc1(P-1) || A's fc2 operand
-        half_step(BlkA(), BlkB(), Last());
+        half_step(BlkA(), BlkB(), Last(), Pos0());
         if (traced2) stamp(a, wave, lane, 25);
         deal(std::integral_constant<int, kFc1M>(), [&](auto Ic) { fc1_i(BlkB(), Ic); }, [&](auto Sc) { split_q(BlkA(), Sc, h1[0], ds1); });
 

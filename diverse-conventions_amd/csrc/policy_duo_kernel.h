@@ -46,7 +46,8 @@ __device__ __forceinline__ void oc_pin_interleave() {
     }
 }
 
-template <int NDIG, bool FC1_LDS>
+// GW, GH: the grid this build is for (0, 0: any grid, read from the launch arguments) -- see policy_duo_body.h
+template <int NDIG, bool FC1_LDS, int GW = 0, int GH = 0>
 __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) {
     // (names and constants the one-block body, included below for single blocks, expects from its kernel)
     constexpr bool CONV_LDS = false, TAIL_LDS = true, FOLD = false;

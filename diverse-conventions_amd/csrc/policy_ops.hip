@@ -1317,17 +1317,38 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     // single-grid launches only: gather tiles, select codes, several grids, wave tiles and the diagnostics' fold / forced plans stay
     // on oc_policy_kernel.  OC_POLICY_DUO=0 (read per call) keeps every launch there, for A/B runs and plan-equality checks.
     bool duo = !multi && !wave_tiles && !gather && !fold && !s0.row_select && !(env_plan && env_plan[0]);
-    if (duo) { const char *v = getenv("OC_POLICY_DUO"); if (v && v[0] == '0') duo = false; }
+    if (duo) {
+        // Which launches: a pair costs 12.9 us where two wavefronts of a SIMD take 13.5 for their two blocks (steady state: -5 %,
+        // profiles/r06_trace_policy_duo.log), but a stretch's LAST blocks, when fewer than five are left over from the rounds of eight,
+        // run as single blocks on wavefronts of their own (~7 us with three SIMDs of the CU idle): 131 070 rows on 256 workgroups
+        // (16.05 blocks each: one left over) 38.9 us against 36.4, 245 760 rows on 240 (32 each) 52.3 against 55.3.  So: by default
+        // only launches whose workgroups get whole rounds -- equal tiles of a multiple of eight blocks -- or leave five or more over.
+        // OC_POLICY_DUO=1 forces it wherever it fits, =0 keeps every launch on oc_policy_kernel (A/B runs, plan-equality checks).
+        const char *v = getenv("OC_POLICY_DUO");
+        if (v && v[0] == '0') duo = false;
+        else if (!(v && v[0] == '1')) {
+            const long long blocks = (s0.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+            const long long wgs = a.n_tiles > 0 ? a.n_tiles : 1, per = blocks / wgs, over = blocks - per * wgs;
+            const bool planned = a.n_tiles >= 128;                        // (what launch_policy below takes as one tile per workgroup, or close to it)
+            // every workgroup's stretch (per or per + 1 blocks) is whole rounds of eight or leaves five or more over
+            auto fits = [](long long t) { return t % 8 == 0 || t % 8 >= 5; };
+            duo = planned && per >= 8 && fits(per) && (over == 0 || fits(per + 1));
+        }
+    }
     bool duo_fc1 = false;
     if (duo) {
         duo_fc1 = kb(w_tail_all + 32) + 8 * obs1 <= kLds;
         if (kb((duo_fc1 ? w_tail_all : w_tail_small) + 32) + 8 * obs1 > kLds) duo = false;
     }
     size_t lds_duo = 0;
+    int duo_grid = 0;                                                 // 0: the generic duo build, 1 / 2: the builds for the 5x4 / 5x5 grid
     if (duo) {
         static const kernel_t kernels_duo[4][2] = {{oc_policy_duo_kernel<1, false>, oc_policy_duo_kernel<1, true>}, {oc_policy_duo_kernel<2, false>, oc_policy_duo_kernel<2, true>},
                                                    {oc_policy_duo_kernel<3, false>, oc_policy_duo_kernel<3, true>}, {oc_policy_duo_kernel<4, false>, oc_policy_duo_kernel<4, true>}};
         kernel = kernels_duo[digits - 1][duo_fc1 ? 1 : 0];
+        // builds for ONE grid (offsets known at compile time, position loop unrolled): the classic layouts' small grids, three digits
+        if (digits == 3 && !duo_fc1 && s0.L.W == 5 && s0.L.H == 4) { kernel = oc_policy_duo_kernel<3, false, 5, 4>; duo_grid = 1; }
+        if (digits == 3 && !duo_fc1 && s0.L.W == 5 && s0.L.H == 5) { kernel = oc_policy_duo_kernel<3, false, 5, 5>; duo_grid = 2; }
         waves = 4;
         fc1_lds = duo_fc1;
         conv_lds = false;
@@ -1340,8 +1361,8 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     if (dev < 0 || dev >= 64) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: device %d out of range", dev);
     const OcDeviceScope on_device(dev);
     if (!on_device.ok) return oc_internal_fail(OC_ERR_HIP, "oc_policy_forward: cannot make device %d current", dev);
-    static size_t lds_granted[64][4][2][2][6] = {};                   // largest opt-in already set per device and kernel instance
-    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][duo ? 5 : wave_tiles ? 2 : multi ? 1 : gather ? 3 : fold ? 4 : 0];
+    static size_t lds_granted[64][4][2][2][8] = {};                   // largest opt-in already set per device and kernel instance
+    size_t &granted = lds_granted[dev][digits - 1][fc1_lds ? 1 : 0][conv_lds ? 1 : 0][duo ? 5 + duo_grid : wave_tiles ? 2 : multi ? 1 : gather ? 3 : fold ? 4 : 0];
     const size_t lds_use = duo ? lds_duo : lds;
     if (lds_use > 64 * 1024 && lds_use > granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

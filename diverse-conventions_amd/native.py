@@ -316,7 +316,7 @@ def aot_default_shapes():
     shapes = []
     for name in CLASSIC_LAYOUTS:
         shapes += [(P(name), 65536), (P(name), 8192)]
-    shapes += [(P("cramped_room"), 4096), (P("cramped_room"), 65535), (P("cramped_room"), 1000), (P("cramped_room"), 65471),
+    shapes += [(P("cramped_room"), 4096), (P("cramped_room"), 65535), (P("cramped_room"), 65280), (P("cramped_room"), 1000), (P("cramped_room"), 65471),
                (P("asymmetric_advantages"), 8184), (P("asymmetric_advantages"), 65536 // 2), (P("asymmetric_advantages"), 65536 // 4)]
     groups = [[(P(name), 8192) for name in CLASSIC_LAYOUTS]]
     return shapes, groups

@@ -18,7 +18,7 @@ with open(os.path.join(G, f"{tag}_pmc_fused_policy_all.csv")) as f, open(os.path
     header = next(r)
     w.writerow(header)
     ki = header.index("Kernel_Name")
-    rows = [row for row in r if "oc_policy_kernel" in row[ki]]
+    rows = [row for row in r if "oc_policy_kernel" in row[ki] or "oc_policy_duo_kernel" in row[ki]]
     w.writerows(rows)
 counters = {}
 di, ci, vi = header.index("Dispatch_Id"), header.index("Counter_Name"), header.index("Counter_Value")
@@ -46,7 +46,7 @@ print(f"N = 1 line: {line['value'] / 1e9:.2f} G agent-env steps/s, {line['roofli
       f"{line['policy_in_loop']['us_per_step']:.1f} us per step (policy launch {line['policy_in_loop']['policy_kernel']['us_per_launch']:.1f}); "
       f"config 4's share {line['config4_share_policy_in_loop']['us_per_step']:.1f}; mixed play {line['mixed_play']['us_per_step']:.1f}")
 print(f"rocprofv3: oc_jit_step_i32_v16 {k['Calls']} calls, average {float(k['AverageNs']):.0f} ns")
-for frag in ("oc_jit_step_i32_v16_nt", "oc_jit_step_i32_v16_pl", "oc_policy_kernel", "np_group_kernel"):
+for frag in ("oc_jit_step_i32_v16_nt", "oc_jit_step_i32_v16_pl", "oc_policy_kernel", "oc_policy_duo_kernel", "np_group_kernel"):
     n, r = pick(frag)
     if n:
         print(f"  with secondaries: {n[:60]} {r['Calls']} calls, average {float(r['AverageNs']):.0f} ns")
