@@ -283,6 +283,26 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
     got = runs[-1][0]
     gather_ms = sum(r[1] for r in runs) / reps
     feat_ms = sum(r[2] for r in runs) / reps
+    # what round 3's path paid on top: one concatenation of the four loose fields into a send buffer (read + write of the shard)
+    cat_ms = None
+    if not on_host:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        loose = (traj.records.reshape(-1), traj.actions.reshape(-1), traj.reward.reshape(-1), traj.done.reshape(-1))
+        torch.cat(loose)
+        e0.record()
+        torch.cat(loose)
+        e1.record()
+        torch.cuda.synchronize()
+        cat_ms = e0.elapsed_time(e1)
+    # check: own fields come back at index `rank`, and every peer's block of the re-featurised tensor has the checksum its owner
+    # computed from its own engine's observation of that slot
+    own = {"records": send.wire[:traj.records.numel()].view(traj.records.shape)}
+    ok = bool(torch.equal(got["records"][rank], own["records"]))
+    ok = ok and all(torch.equal(got[k][rank].to(dev), getattr(traj, k)) for k in ("actions", "reward", "done"))
+    for r in range(world):
+        for t in probe_t:
+            ok = ok and _checksum(out[t, :, r * n:(r + 1) * n]) == tuple(sums_all[r][t])
+    # (after the checks of the one-shot exchange above: what follows rolls the trajectory out again)
     # ---- the same update with the exchange CHUNKED and OVERLAPPED with the rollout (ChunkedGather): the rollout's
     # launches fill the wire buffer chunk by chunk on the current stream; behind each chunk's last step a side stream all-gathers the
     # chunk's record slots and re-featurises them.  exposed = (rollout with the overlapped exchange) - (the same rollout alone).
@@ -333,25 +353,6 @@ def exchange_leg(world, rank, local, backend, gen, c4_step_s, regions):
         rollout_alone_ms, overlap_total_ms = min(alone) * 1e3, min(both) * 1e3
         exposed_ms = max(0.0, overlap_total_ms - rollout_alone_ms)
         del out2
-    # what round 3's path paid on top: one concatenation of the four loose fields into a send buffer (read + write of the shard)
-    cat_ms = None
-    if not on_host:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        loose = (traj.records.reshape(-1), traj.actions.reshape(-1), traj.reward.reshape(-1), traj.done.reshape(-1))
-        torch.cat(loose)
-        e0.record()
-        torch.cat(loose)
-        e1.record()
-        torch.cuda.synchronize()
-        cat_ms = e0.elapsed_time(e1)
-    # check: own fields come back at index `rank`, and every peer's block of the re-featurised tensor has the checksum its owner
-    # computed from its own engine's observation of that slot
-    own = {"records": send.wire[:traj.records.numel()].view(traj.records.shape)}
-    ok = bool(torch.equal(got["records"][rank], own["records"]))
-    ok = ok and all(torch.equal(got[k][rank].to(dev), getattr(traj, k)) for k in ("actions", "reward", "done"))
-    for r in range(world):
-        for t in probe_t:
-            ok = ok and _checksum(out[t, :, r * n:(r + 1) * n]) == tuple(sums_all[r][t])
     stats = torch.tensor([gather_ms, feat_ms, 0.0 if (ok and chunk_ok) else 1.0, exposed_ms or 0.0, overlap_total_ms or 0.0, rollout_alone_ms or 0.0],
                          dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist.is_initialized():

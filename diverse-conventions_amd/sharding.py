@@ -272,6 +272,7 @@ class ChunkedGather:
             self.small = self.ex.all_gather(send)                           # [world, words of actions | reward | done]
         if self.cuda:
             torch.cuda.current_stream(send.device).wait_stream(self.stream)
+        self.submitted = 0                                            # (the next update's rollout may reuse this object and its buffers)
         res = {"records": self.chunk_views}
         for name in ("actions", "reward", "done"):
             off, shape = self.fields[name]
