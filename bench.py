@@ -904,8 +904,7 @@ def main():
                                               "work between the layers does not overlap the matrix pipe on a gfx950 SIMD, DESIGN.md 9a"}}
           eng2.close()
           # the same rollout with the kitchens per pairing segment a multiple of 32 (aligned_threads: what INTEGRATION.md recommends --
-          # the policy kernel evaluates 32 rows per block): 15 x 4352 kitchens.  Every workgroup's stretch is then whole rounds of
-          # eight blocks, or leaves five or more over, and the launch runs TWO blocks per wavefront (oc_policy_duo_kernel, round 6)
+          # the policy kernel evaluates 32 rows per block): 15 x 4352 kitchens, no ragged block per segment
           from diverse_conventions_amd import aligned_threads
           th_a = aligned_threads(n, k)
           eng2a = OvercookedEngine(params, th_a * (2 * k + 1), local)
@@ -929,7 +928,7 @@ def main():
           rows_a = 2 * eng2a.num_kitchens
           policy["aligned_segments"] = {
               "what": f"the same rollout at aligned_threads({n}, {k}) = {th_a} kitchens per pairing segment ({eng2a.num_kitchens} kitchens): segments of whole "
-                      "32-row blocks; the policy launch runs two blocks per wavefront (oc_policy_duo_kernel)",
+                      "32-row blocks",
               "kitchens": eng2a.num_kitchens, "us_per_step": step_a_us, "value": 2 * eng2a.num_kitchens / step_a_us * 1e6, "unit": "agent-env steps/s",
               "policy_kernel_us_per_launch": pol_a_us, "network_evaluations": rows_a,
               "policy_kernel_frac_of_issue_bound": bound_us * rows_a / rows / pol_a_us, "checked": check_policy_in_loop(ro_a, eng2a, params)}

@@ -1318,11 +1318,13 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     // on oc_policy_kernel.  OC_POLICY_DUO=0 (read per call) keeps every launch there, for A/B runs and plan-equality checks.
     bool duo = !multi && !wave_tiles && !gather && !fold && !s0.row_select && !(env_plan && env_plan[0]);
     if (duo) {
-        // Which launches: a pair costs 12.9 us where two wavefronts of a SIMD take 13.5 for their two blocks (steady state: -5 %,
-        // profiles/r06_trace_policy_duo.log), but a stretch's LAST blocks, when fewer than five are left over from the rounds of eight,
-        // run as single blocks on wavefronts of their own (~7 us with three SIMDs of the CU idle): 131 070 rows on 256 workgroups
-        // (16.05 blocks each: one left over) 38.9 us against 36.4, 245 760 rows on 240 (32 each) 52.3 against 55.3.  So: by default
-        // only launches whose workgroups get whole rounds -- equal tiles of a multiple of eight blocks -- or leave five or more over.
+        // Which launches (profiles/r06_*policy*.log): in the steady state a pair costs 11.4-12.9 us where the two wavefronts of a SIMD
+        // take 13.5 for their two blocks (-5..-8 %: 245 760 rows on 240 workgroups, 32 blocks each, 52.5 us against 57.2), but (i) a
+        // wavefront's FIRST pair is slower than eight wavefronts' first blocks (cold code, rows and fc1 fragments from furthest away
+        // with half as many wavefronts to hide it: 130 560 rows, 16 blocks per workgroup, 38.1 against 37.1) and (ii) a stretch's last
+        // blocks, when fewer than five are left over from the rounds of eight, run as single blocks on wavefronts of their own (~7 us
+        // with three SIMDs of the CU idle: 131 070 rows, one block left over, 38.5 against 37.1).  So by default only launches of three
+        // rounds or more per workgroup whose stretches are whole rounds or leave five or more blocks over.
         // OC_POLICY_DUO=1 forces it wherever it fits, =0 keeps every launch on oc_policy_kernel (A/B runs, plan-equality checks).
         const char *v = getenv("OC_POLICY_DUO");
         if (v && v[0] == '0') duo = false;
@@ -1332,7 +1334,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
             const bool planned = a.n_tiles >= 128;                        // (what launch_policy below takes as one tile per workgroup, or close to it)
             // every workgroup's stretch (per or per + 1 blocks) is whole rounds of eight or leaves five or more over
             auto fits = [](long long t) { return t % 8 == 0 || t % 8 >= 5; };
-            duo = planned && per >= 8 && fits(per) && (over == 0 || fits(per + 1));
+            duo = planned && per >= 24 && fits(per) && (over == 0 || fits(per + 1));
         }
     }
     bool duo_fc1 = false;

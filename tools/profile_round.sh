@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 pick() { find "$1" -name "*_$2.csv" | head -1; }
 
-rm -rf $OUT/prof_${R}_ns $OUT/prof_${R}_ws $OUT/pmc_${R}_w $OUT/pmc_${R}_f $OUT/pmc_${R}_pol
+rm -rf $OUT/prof_${R}_ns $OUT/prof_${R}_ws $OUT/pmc_${R}_w $OUT/pmc_${R}_f $OUT/pmc_${R}_pol $OUT/pmc_${R}_pol0
 echo "[1/6] kernel stats, headline workload only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${R}_ns -- python3 $REPO/bench.py --steps 1000 --warmup 200 --no-cpu-baseline --no-secondary > $OUT/${R}_bench_under_rocprof.log 2>&1
 cp "$(pick $OUT/prof_${R}_ns kernel_stats)" $OUT/${R}_kernel_stats.csv
@@ -28,6 +28,12 @@ echo "[5/6] policy kernel counters"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_${R}_pol -- python3 $REPO/tools/pmc_policy.py > $OUT/${R}_pmc_pol.log 2>&1
 cp "$(pick $OUT/pmc_${R}_pol counter_collection)" $OUT/${R}_pmc_fused_policy_all.csv
 cp "$(pick $OUT/pmc_${R}_pol kernel_trace)" $OUT/${R}_pmc_fused_policy_trace.csv
+echo "[5b] policy kernel counters, one block per wavefront (OC_POLICY_DUO=0)"
+export OC_POLICY_DUO=0
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_${R}_pol0 -- python3 $REPO/tools/pmc_policy.py > $OUT/${R}_pmc_pol0.log 2>&1
+unset OC_POLICY_DUO
+cp "$(pick $OUT/pmc_${R}_pol0 counter_collection)" $OUT/${R}_pmc_fused_policy_noduo_all.csv
+cp "$(pick $OUT/pmc_${R}_pol0 kernel_trace)" $OUT/${R}_pmc_fused_policy_noduo_trace.csv
 echo "[6/6] the plain bench line"
 cd $REPO && python3 bench.py > $OUT/${R}_bench_n1.log 2> $OUT/${R}_bench_n1.err
 echo done
