@@ -53,7 +53,7 @@ def test_product_library_carries_no_diagnostics():
     for needle in (b"OC_ABLATE", b"OC_FOLD", b"OC_POLICY_FOLD", b"OC_STORE_MODE", b"OC_POLICY_PLAN", b"OC_JIT_TRACE", b"OC_MIN_WAVES", b"fold_env_group",
                    b"fold_expected_kernel"):
         assert needle not in blob, needle
-    for kept in (b"OC_NO_JIT", b"OC_JIT_CACHE", b"OC_DWORD_STORES", b"OC_POLICY_COOP"):      # the documented switches of the product
+    for kept in (b"OC_NO_JIT", b"OC_JIT_CACHE", b"OC_DWORD_STORES", b"OC_POLICY_COOP", b"OC_POLICY_DUO"):      # the documented switches of the product
         assert kept in blob, kept
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
     assert not [s for s in native.SYMBOLS_DIAG + native.SYMBOLS_EXPERIMENTS if s in nm]
