@@ -40,6 +40,19 @@ def test_bench_two_ranks_one_json_line(clean_launcher):
     ex1 = j1["exchange"]
     assert ex1["checked"] is True and ex1["rccl"]["backend"] == "nccl" and ex1["rccl"]["world"] == 1 and ex1["rccl"]["version"] and ex1["steps"] == 200
     assert ex1["record_step_us"]["one_launch_with_record_destination"] < ex1["record_step_us"]["step_plus_export_states"]
+    # round 6: the chunked, overlapped form of the same exchange is timed beside it (what the update waits for beyond the rollout) ...
+    ov = ex1["overlap"]
+    assert ex1["exposed_ms"] >= 0 and ov["collectives_per_update"] == ov["chunks"] + 1 == 9 and ov["rollout_with_overlapped_exchange_ms"] >= ov["rollout_alone_ms"] > 0
+    assert ex1["update_amortised_value"] >= ex1["update_amortised_serial_value"] * 0.9
+    # ... no hiprtc build ran inside any timed region (the step + export_states leg read 2978 us "per step" in round 5's driver record)
+    assert j1["jit_builds_inside_timed_regions"] == 0 and j2["jit_builds_inside_timed_regions"] == 0 and j1["jit_builds"]["timed_regions"] >= 10
+    assert ex1["record_step_us"]["step_plus_export_states"] < 100
+    # ... the line separates host cost from kernel time and says where the in-place planes live
+    assert j1["host_fixed_us"] > 0 and j1["value_kernel_time"] > j1["value"] and j1["wall_with_barrier_ms"] >= j1["ms_per_step"] * j1["steps"] * 0.99
+    r = j1["roofline"]
+    assert r["fits_infinity_cache"] is True and abs(r["destination_MB"] - 52.4) < 0.1 and 0.5 < r["frac_hbm_proper"] < r["frac"] < 1
+    assert j1["fused_rollout"]["fits_infinity_cache"] is True and j1["config4_split"]["fits_infinity_cache"] is True
+    assert set(j1["cold_start"]["oc_create_ms_8192_kitchens"]) == {"simple", "unident_s", "random1", "random0", "random3"}
     # ... and config 2 is in the line
     assert j1["config2"]["kitchens"] == 4096 and 0 < j1["config2"]["frac_of_8TBps"] < 1 and j1["config2"]["fused_rollout_us_per_step"] < j1["config2"]["us_per_launch"]
     # the exchange leg: config 4's compact trajectory through the one all-gather + featurize_all, both ranks' blocks checked
