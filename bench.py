@@ -472,7 +472,8 @@ def drop_in_and_eval_legs(local, regions, gen):
                     oracle afterwards (rewards and dones bit-identical)."""
     import numpy as np
     import torch
-    from diverse_conventions_amd import FusedVectorAgent, OvercookedMadrona, PackedNetworks, RandomVectorAgent, VectorAgent, get_base_layout_params
+    from diverse_conventions_amd import (FusedVectorAgent, OvercookedMadrona, PackedNetworks, RandomVectorAgent, VectorAgent, VectorMultiAgentEnv,
+                                         get_base_layout_params)
     from oracle import oracle
     W, H = 5, 4
     P = (W - 2) * (H - 2)
@@ -528,16 +529,19 @@ def drop_in_and_eval_legs(local, regions, gen):
         with regions:
             kern_us = env.sim.rollout_timed(flat, 500) * 1e3 / 500
         case = {"kitchens": n, "env_kernel_us": kern_us}
-        for name in ("random_partner", "random_partner_graph_step", "torch_actor_partner"):
+        for name in ("random_partner", "random_partner_stacked", "random_partner_graph_step", "torch_actor_partner"):
             tick = [0]
             agent = TorchActor(sds[1], dev) if name == "torch_actor_partner" else RandomVectorAgent(lambda: par[tick[0] % t_act])
             env.partners[0].clear()
             env.add_partner_agent(agent)
             env._graph_step = name == "random_partner_graph_step"   # n_step replays a one-launch HIP graph of the env step instead of enqueueing it
+            # (_stacked: the reference's own VectorMultiAgentEnv.step -- torch.stack into [P, N, 1], then n_step -- instead of the class's
+            # two-buffer step, oc_step_players)
+            step_fn = (lambda act: VectorMultiAgentEnv.step(env, act)) if name == "random_partner_stacked" else env.step
             env.reset()
             for t in range(60):
                 tick[0] = t
-                env.step(ego[t % t_act])
+                step_fn(ego[t % t_act])
             torch.cuda.synchronize()
             best = None
             for _ in range(2):
@@ -545,7 +549,7 @@ def drop_in_and_eval_legs(local, regions, gen):
                     t0 = time.perf_counter()
                     for t in range(T):
                         tick[0] = t
-                        env.step(ego[t % t_act])
+                        step_fn(ego[t % t_act])
                     t1 = time.perf_counter()
                     torch.cuda.synchronize()
                     t2 = time.perf_counter()
@@ -556,8 +560,9 @@ def drop_in_and_eval_legs(local, regions, gen):
             case[name] = best
         env.close()
         drop["cases"].append(case)
-    drop["note"] = ("host-bound when host_enqueue_us_per_step ~ us_per_step: the Python of one step (partner call, torch.stack into the "
-                    "persistent [P, N, 1] buffer, one ctypes call, cached ego view) costs more than the kernel; `_graph_step` replays the env "
+    drop["note"] = ("host-bound when host_enqueue_us_per_step ~ us_per_step: the Python of one step costs more than the kernel.  The class's own "
+                    "step hands the ego's and the partner's action tensors to the kernel as they are (oc_step_players, round 6); `_stacked` is the "
+                    "reference's way (partner call, torch.stack into the persistent [P, N, 1] buffer, n_step); `_graph_step` replays the env "
                     "launch as a one-kernel HIP graph (OvercookedMadrona(graph_step=True)) -- a graph of one kernel saves nothing, the cost is "
                     "the Python around it; the C-enqueued loops of this line (`value`, policy_in_loop) are what a runner that hands the loop "
                     "to the library gets")
@@ -583,7 +588,8 @@ def drop_in_and_eval_legs(local, regions, gen):
             obs, newreward, done, _ = env.step(action)
             reward += newreward / 20
             if record:
-                rec_actions[i].copy_(env._actions.view(2, n))
+                rec_actions[i, 0].copy_(ego_agent.actions)       # (FusedVectorAgent keeps its last actions; the env read both buffers as they were)
+                rec_actions[i, 1].copy_(alt_agent.actions)
                 rec_rew[i].copy_(newreward)
                 rec_done[i].copy_(done)
         return reward

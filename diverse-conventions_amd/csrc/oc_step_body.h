@@ -111,7 +111,9 @@ __device__ __forceinline__ int interact(bool act, uint32_t terr, uint32_t &t, ui
 // into a flat instruction, which counts on vmcnt as well -- each LDS read then waits for all plane stores in flight (measured:
 // 2 us per flush group instead of 0.2).
 // COHERENT: the action buffer was filled earlier in the same launch (see load_action).
-template <bool STEP, bool ACT64, bool VEC16, int QN, int SM = SM_PLAIN, bool FUSED = false, bool BATCH = false, bool COHERENT = false>
+// TWOPTR: the two players' actions arrive as two [N] buffers (a.actions, a.actions1) instead of one [P][N] tensor -- the drop-in
+// classes hand the ego's and the partner's action tensors over as they are (oc_step_players), no assembly pass in front of the step.
+template <bool STEP, bool ACT64, bool VEC16, int QN, int SM = SM_PLAIN, bool FUSED = false, bool BATCH = false, bool COHERENT = false, bool TWOPTR = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id, const int n_blocks, int lds_dword_offset = 0, int lane_id = -1) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
     uint32_t *const lds = lds_all + lds_dword_offset;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, const int block_id,
                 pa1 = static_cast<int>(oc_hash_action(a.rng_seed, static_cast<uint32_t>(kid), a.rng_t0, 1));
             } else {
                 pa0 = load_action<ACT64, COHERENT>(a.actions, kid);
-                pa1 = load_action<ACT64, COHERENT>(a.actions, KP_n_kitchens(a) + kid);
+                pa1 = TWOPTR ? load_action<ACT64, COHERENT>(a.actions1, kid) : load_action<ACT64, COHERENT>(a.actions, KP_n_kitchens(a) + kid);
             }
         } else {
             pa0 = pa1 = A_STAY;

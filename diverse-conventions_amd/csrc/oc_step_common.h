@@ -201,6 +201,9 @@ struct StepArgs {
     uint4 *state_out;
     int32_t ablate;             // diagnostics build only (tools/ablate.py): phases to skip; always 0 in the product library
     unsigned long long *trace;  // diagnostics build only: [wave][8] s_memrealtime stamps (100 MHz); always NULL in the product library
+    // TWOPTR kernels only (oc_step_players, round 6): player 1's actions [N], a buffer of its own -- `actions` is then player 0's [N].
+    // Every other kernel reads player 1's at actions + N (one [P][N] tensor) and never looks at this field.
+    const void *actions1;
 };
 
 // One launch over several engines (oc_group_step / oc_group_observe): blocks [first_block[s], first_block[s+1]) of the

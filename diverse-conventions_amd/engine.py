@@ -17,6 +17,13 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+try:                                    # the current stream's raw handle without building a torch.cuda.Stream object
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover - older torch
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 def pack_states(tiles, players, timestep, record_bytes):
     """Fixture serialisation (tiles int8 [N,S,4], players int8 [N,P,6], timestep int32 [N]) ->
     native state records uint32 [N, record_bytes/4] (layouts: include/overcooked_hip.h; P = 2 packs both players'
@@ -90,6 +97,7 @@ class OvercookedEngine:
                                  ctypes.byref(handle)))
         self._handle = handle
         self._L = L
+        self._players_argv = None
         self.record_bytes = int(L.oc_state_record_bytes(handle))
         n = self.num_kitchens
         with torch.cuda.device(self.device):
@@ -112,7 +120,9 @@ class OvercookedEngine:
             pass
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (the raw handle of the current stream: torch.cuda.current_stream(...).cuda_stream builds a Stream object first, 1.9 us of
+        # the 7.4 us a Python-driven step spent in this module, tools/exp_drop_in_breakdown.py)
+        return _raw_stream(self.device.index)
 
     # ------------------------------------------------------------------ hot path
     def _actions(self, actions):
@@ -151,6 +161,28 @@ class OvercookedEngine:
         rec, _ = self._records_arg(records)
         native.check(self._L.oc_step(self._handle, _ptr(a), dt, _ptr(obs), _ptr(reward), _ptr(done), rec, self._stream()))
         return obs, reward, done
+
+    def step_players(self, per_player):
+        """One step from the two players' action tensors as they are -- `per_player` = [player 0's, player 1's], each N int32 / int64
+        values on the engine's device, same dtype, contiguous -- into the engine's own buffers, without assembling a [P, N] tensor
+        (oc_step_players).  -> True, or False when this call cannot be served that way (the caller then stacks and calls `step`)."""
+        if self.num_players != 2:
+            return False
+        a0, a1 = per_player
+        n = self.num_kitchens
+        if (a0.dtype != a1.dtype or a0.dtype not in (torch.int32, torch.int64) or a0.device != self.device or a1.device != self.device
+                or a0.numel() != n or a1.numel() != n or not a0.is_contiguous() or not a1.is_contiguous()):
+            return False
+        if self._players_argv is None:
+            self._players_argv = (ctypes.c_void_p * 2)()
+            self._own_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr())
+        self._players_argv[0], self._players_argv[1] = a0.data_ptr(), a1.data_ptr()
+        rc = self._L.oc_step_players(self._handle, self._players_argv, native.OC_ACT_I64 if a0.dtype == torch.int64 else native.OC_ACT_I32,
+                                     self._own_ptrs[0], self._own_ptrs[1], self._own_ptrs[2], _raw_stream(self.device.index))
+        if rc == -2:                    # OC_ERR_UNSUPPORTED: a fresh destination before, another kernel build ...
+            return False
+        native.check(rc)
+        return True
 
     def observe(self, obs=None):
         obs = self.obs if obs is None else obs

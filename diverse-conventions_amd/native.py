@@ -46,7 +46,7 @@ STATUS_NAMES = {0: "OC_OK", -1: "OC_ERR_INVALID_ARG", -2: "OC_ERR_UNSUPPORTED", 
 # every symbol the public headers declare (tests/test_abi.py checks header text, these lists and the library's export table
 # against each other): include/overcooked_hip.h -- the environment: engines, groups, state ...
 SYMBOLS_ENV = [
-    "oc_create", "oc_destroy", "oc_step", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
+    "oc_create", "oc_destroy", "oc_step", "oc_step_players", "oc_observe", "oc_reset_all", "oc_episode_control", "oc_rollout", "oc_rollout_timed", "oc_rollout_fused", "oc_synthetic_action",
     "oc_encode_states", "oc_encode_states_strided", "oc_encode_trajectory",
     "oc_group_create", "oc_group_destroy", "oc_group_size", "oc_group_step", "oc_group_observe", "oc_group_rollout_timed",
     "oc_group_set_tuning", "oc_group_build_info", "oc_state_record_bytes", "oc_get_state", "oc_set_state", "oc_export_states",
@@ -179,6 +179,7 @@ def lib():
     L.oc_create.argtypes = [ctypes.POINTER(OcLayoutParams), i64, i32, ctypes.POINTER(vp)]
     L.oc_destroy.argtypes = [vp]
     L.oc_step.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.oc_step_players.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, vp]
     L.oc_observe.argtypes = [vp, vp, vp]
     L.oc_reset_all.argtypes = [vp, vp, vp]
     L.oc_episode_control.argtypes = [vp, vp, vp, vp]

@@ -107,6 +107,32 @@ class OvercookedMadrona(VectorMultiAgentEnv):
             self.sim.step(actions)
         self._graph_actions_ptr = actions.data_ptr()
 
+    def step(self, action):
+        """VectorMultiAgentEnv.step (pantheonrl_extension/vectorenv.py:171-193) for the common case -- two players, everything on the
+        GPU, integer action tensors -- without assembling the [P, N, 1] action tensor: the ego's and the partner's tensors go to the
+        kernel as they are (oc_step_players; torch.stack was 7 of a step's 18 us).  Same calls on the partner (get_action with its
+        observation, then update), same return values; `self._actions` is only refreshed on the general path."""
+        if self._on_device and self.n_players == 2 and not self._graph_step and self._obs:
+            other = 1 - self.ego_ind
+            pact = self._current(0).get_action(self._obs[other])
+            if torch.is_tensor(action) and torch.is_tensor(pact):
+                pair = [action, pact] if self.ego_ind == 0 else [pact, action]
+                if self.sim.step_players(pair):
+                    self._obs = self.get_obs()
+                    rews, done = self.static_rewards, self.static_dones
+                    self._update_players(rews, done)
+                    return self._obs[self.ego_ind], rews[self.ego_ind], done, self.infos
+            # the general path, with the partner's action already drawn (an agent must not be asked twice for one step)
+            per_player = [action, pact] if self.ego_ind == 0 else [pact, action]
+            if self._actions is None:
+                self._actions = torch.stack(per_player)
+            else:
+                torch.stack(per_player, out=self._actions)
+            self._obs, rews, done, info = self.n_step(self._actions)
+            self._update_players(rews, done)
+            return self._obs[self.ego_ind], rews[self.ego_ind], done, info
+        return super().step(action)
+
     def n_reset(self):
         # like the reference (envs/overcooked2_env.py:127-128) this re-reads the observation of the
         # running episodes; kitchens only reset inside step() when they reach the horizon

@@ -63,7 +63,7 @@ extern "C" {
 #define OC_MAX_TILES 255
 #define OC_MAX_PLAYERS 4
 #define OC_NUM_ACTIONS 6
-#define OC_ABI_VERSION 6
+#define OC_ABI_VERSION 7
 
 typedef enum {
     OC_OK = 0,
@@ -107,6 +107,15 @@ int oc_destroy(oc_engine *e);
  * compact trajectory of the exchange (oc_encode_trajectory re-featurises it on the receiver). */
 int oc_step(oc_engine *e, const void *d_actions, int action_dtype, int8_t *d_obs, int32_t *d_reward,
             int32_t *d_done, void *d_records, void *stream);
+
+/* oc_step with the two players' actions in two device buffers, d_actions[0] = player 0's [N], d_actions[1] = player 1's [N] (a
+ * host array of two device pointers, same dtype): what VectorMultiAgentEnv.step holds before it assembles Manager's [P, N, 1] action
+ * tensor (pantheonrl_extension/vectorenv.py:171-193, envs/overcooked2_env.py:116-119) -- the kernel reads them where they are, no
+ * assembly pass.  Same results as oc_step on the stacked tensor.  Serves in-place destinations (d_obs = the previous step's) of
+ * 2-player engines on the specialised kernel; anything else returns OC_ERR_UNSUPPORTED (stack and call oc_step).  The entry points
+ * are a module of their own, built on first use or by oc_prepare_kernels. */
+int oc_step_players(oc_engine *e, const void *const *d_actions, int action_dtype, int8_t *d_obs, int32_t *d_reward, int32_t *d_done,
+                    void *stream);
 
 /* Observation of the current state without stepping: what OvercookedMadrona.n_reset()/get_obs()
  * return (envs/overcooked2_env.py:103-114,127-128 -- n_reset re-reads, it does not reset). */

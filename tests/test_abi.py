@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], check=True, capture_output=True, text=True).stdout
     exported = sorted({ln.split()[-1] for ln in nm.splitlines() if re.search(r" [TW] oc_[a-z_0-9]+$", ln) and "oc_internal" not in ln})
     assert exported == sorted(declared)
-    assert L.oc_abi_version() == 6
+    assert L.oc_abi_version() == 7
     # the drop-in boundary stays small: no experiment or diagnostic leaks into the two public headers
     assert not [f for f in native.SYMBOLS if f.startswith(("oc_exp_", "oc_debug_")) or "_cus" in f or "cu_" in f]
 
@@ -150,7 +150,7 @@ int main(void) {
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", libdir, "-loc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
-    assert out[0] == "-2" and "players" in out[1] and out[2] == "6" and out[3] == "0"
+    assert out[0] == "-2" and "players" in out[1] and out[2] == "7" and out[3] == "0"
 
 
 def test_code_object_cache_checks_what_it_loads(tmp_path):

@@ -783,3 +783,34 @@ def test_capture_then_an_eager_step_into_a_fresh_slot_then_replay():
     for x, y in zip(eng.get_state(), ora.get_state()):
         assert np.array_equal(x, y)
     eng.close()
+
+
+@pytest.mark.parametrize("layout,n,dtype", [("cramped_room", 4099, torch.int64), ("asymmetric_advantages", 8192, torch.int32), ("coordination_ring", 65536, torch.int64)])
+def test_step_from_two_action_buffers_equals_the_stacked_step(layout, n, dtype):
+    """oc_step_players (round 6): the two players' actions as two [N] buffers -- what VectorMultiAgentEnv.step holds before it stacks
+    them -- against the oracle, and against oc_step on the stacked tensor from the same states; falls back (False) for a destination
+    that is not the previous step's, for mixed dtypes and for non-contiguous tensors."""
+    from diverse_conventions_amd import OvercookedEngine, get_base_layout_params
+    params = get_base_layout_params(layout, 30)
+    eng, twin = OvercookedEngine(params, n, 0), OvercookedEngine(params, n, 0)
+    ora = oracle.OracleVecEnv(params, n, nthreads=8)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for t in range(70):                                      # crosses the horizon twice
+        a0 = torch.randint(0, 6, (n, 1), device="cuda", dtype=dtype, generator=g)
+        a1 = torch.randint(0, 6, (n,), device="cuda", dtype=dtype, generator=g)
+        assert eng.step_players([a0, a1]) is True, t
+        twin.step(torch.stack([a0.view(-1), a1]))
+        oobs, orew, odone = ora.step(torch.stack([a0.view(-1), a1]).cpu().numpy())
+        assert np.array_equal(eng.obs.cpu().numpy(), oobs), t
+        assert np.array_equal(eng.reward.cpu().numpy(), orew) and np.array_equal(eng.done.cpu().numpy().astype(bool), np.asarray(odone).astype(bool)), t
+        assert torch.equal(eng.obs, twin.obs) and torch.equal(eng.reward, twin.reward) and torch.equal(eng.export_states(), twin.export_states())
+    a0 = torch.randint(0, 6, (n,), device="cuda", dtype=dtype, generator=g)
+    a1 = torch.randint(0, 6, (n,), device="cuda", dtype=dtype, generator=g)
+    assert eng.step_players([a0, a1.to(torch.int32 if dtype == torch.int64 else torch.int64)]) is False      # mixed dtypes
+    assert eng.step_players([a0, torch.stack([a1, a1], dim=1)[:, 0]]) is False                               # not contiguous
+    slot = torch.zeros_like(eng.obs)
+    eng.step(torch.stack([a0, a1]), obs=slot)                # a step into another destination ...
+    assert eng.step_players([a0, a1]) is False               # ... and the next one into the engine's own buffer is not "in place": the caller stacks
+    eng.step(torch.stack([a0, a1]))
+    assert eng.step_players([a0, a1]) is True
+    eng.close(); twin.close()
