@@ -39,7 +39,9 @@ def _ptr(t):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    from .engine import _raw_stream                     # (the raw handle: no torch.cuda.Stream object per call)
+    d = torch.device(device)
+    return _raw_stream(d.index if d.index is not None else torch.cuda.current_device())
 
 
 DEFAULT_DIGITS = 3          # base-256 conv weight digits: 24 bits, the mantissa of the f32 weights (csrc/policy_pack.h)
