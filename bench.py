@@ -986,7 +986,7 @@ def main():
 
     # Secondary figure, never `value`: BASELINE config 2 -- cramped_room, 4096 kitchens, step + encode kernel only: per launch
     # (launch-bound: 4 MB per step) and as the K-steps-per-launch rollout
-    config2 = None
+    config2 = config4_share_env_only = None
     if world == 1 and not args.no_secondary:
         c2_n = 4096
         c2_params = get_base_layout_params("cramped_room", 200)
@@ -1012,6 +1012,22 @@ def main():
                    "note": "one launch per step is launch-bound at this size (a wavefront's own critical path is ~3.4 us, DESIGN.md 5); the "
                            "K-steps-per-launch rollout has no launch boundary per step"}
         eng_c2.close()
+        # ... and one GPU's share of BASELINE config 4 as an env step only: asymmetric_advantages x 8192 kitchens (what each of 8 GPUs
+        # steps per launch; VERDICT r05 item 6 asked for it in the line)
+        c4s_params = get_base_layout_params("asymmetric_advantages", 200)
+        eng_c4s = OvercookedEngine(c4s_params, 8192, local)
+        act_c4s = torch.randint(0, 6, (t_act, 2, 8192), generator=gen, device="cuda", dtype=torch.int32)
+        eng_c4s.rollout(act_c4s, SEC_WARMUP)
+        with regions:
+            c4s_us = eng_c4s.rollout_timed(act_c4s, SEC_STEPS) * 1e3 / SEC_STEPS
+        c4s_bytes = algorithmic_bytes(45) * 8192
+        config4_share_env_only = {"what": "BASELINE config 4, one GPU's share of 8, env step only: asymmetric_advantages x 8192 kitchens, one launch per step, in place",
+                                  "steps": SEC_STEPS, "kitchens": 8192, "us_per_launch": c4s_us, "value": 2 * 8192 / c4s_us * 1e6, "unit": "agent-env steps/s",
+                                  "bytes_per_launch": c4s_bytes, "achieved_GBps": c4s_bytes / c4s_us / 1e3, "frac_of_8TBps": c4s_bytes / c4s_us / 1e3 / HBM_PEAK_GBS,
+                                  **destination(2 * 8192 * 45 * 20 / 1e6), "kernel_build": eng_c4s.kernel_build_info,
+                                  "note": "launch-bound: ~2.5 us of dependent-launch cost + a ~3 us per-wavefront chain; round 6: 4 kitchens per group in "
+                                          "workgroups of eight wavefronts (6.5-7.1 us with 8 per group in one-wavefront workgroups)"}
+        eng_c4s.close()
 
     # Secondary figure, never `value`: kitchens with other player counts (the reference's `num_players`: multiplayer_schelling with 4 and 3
     # players, simple_single), one launch per step on the N-player group kernel (csrc/oc_np_kernels.h), outputs in place
@@ -1187,6 +1203,7 @@ def main():
             out["fused_rollout"] = fused
         if config2 is not None:
             out["config2"] = config2
+            out["config4_share_env_only"] = config4_share_env_only
         if nplayer is not None:
             out["nplayer"] = nplayer
         if mixed is not None:
