@@ -61,11 +61,11 @@
         auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
         for (int i = 0; i < p_first; ++i) advance();
         v4i bfr[6];
-        read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
         v16i acc[NDIG];
         conv(acc, bfr);                                               // the first position
         advance();
-        read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);
+        read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
         v16f h1[2];                                                   // accumulators start at the bias (a cooperative block: the leader's do)
         {
             const v4f *bq = reinterpret_cast<const v4f *>(b1);
@@ -122,7 +122,7 @@
             __builtin_amdgcn_sched_barrier(0);
             if (!kLast) {
                 advance();
-                read_bfrags(rowp, (xq * H + yq) * OC_POLICY_C, colstep, bfr);    // position p+2
+                read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);    // position p+2
             }
             __builtin_amdgcn_sched_barrier(0);
             v4i nb1[kPieces];
@@ -224,8 +224,8 @@
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int hi, lo;
-                const v2f t = v2f{v[8 * g + 2 * j], v[8 * g + 2 * j + 1]} * v2f{descale, descale};
-                split_pair(relu_clamp(t.x), relu_clamp(t.y), hi, lo);
+                const float t0 = v[8 * g + 2 * j] * descale, t1 = v[8 * g + 2 * j + 1] * descale;   // (plain multiplies: see combine_pair)
+                split_pair(relu_clamp(t0), relu_clamp(t1), hi, lo);
                 dst[0][j] = hi; dst[1][j] = lo;
             }
         };

@@ -48,7 +48,7 @@ __device__ __forceinline__ void oc_pin_interleave() {
 
 // GW, GH: the grid this build is for (0, 0: any grid, read from the launch arguments) -- see policy_duo_body.h
 template <int NDIG, bool FC1_LDS, int GW = 0, int GH = 0>
-__global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) {
+__global__ __launch_bounds__(256) void oc_policy_duo_kernel(const int4 *pre_tiles, int pre_tile_per_wg, const PolicyArgs a) {
     // (names and constants the one-block body, included below for single blocks, expects from its kernel)
     constexpr bool CONV_LDS = false, TAIL_LDS = true, FOLD = false;
     constexpr bool gather = false, leader = false, in_coop = false;
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const PolicyArgs a) 
 
     long long wg0, wg1, tstart;
     int ti;
+    const int own_tile_word = prefetch_own_tile(pre_tiles, pre_tile_per_wg);
     warm_kernarg<false>();
+    keep_prefetched(own_tile_word);
     stamp(a, wave, lane, 9);
     if (!policy_find_stretch<false>(a, lane, wg0, wg1, ti, tstart)) return;
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);

@@ -143,7 +143,9 @@ def build(force=False, verbose=False):
     objdir = tempfile.mkdtemp(prefix="obj_asan." if SANITIZE else "obj_diag." if DIAGNOSTICS else "obj.", dir=os.path.join(REPO_ROOT, "build"))
     try:
         objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in SOURCES]
-        cmds = [common + ["-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
+        # policy_ops.hip: its kernels' two leading scalar arguments (table pointer, tiles per workgroup) preloaded into SGPRs (prefetch_own_tile)
+        extra = {"policy_ops.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=4"]}
+        cmds = [common + extra.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
         if verbose:
             for c in cmds:
                 print(" ".join(c))
