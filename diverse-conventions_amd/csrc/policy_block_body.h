@@ -12,10 +12,16 @@
         trace_done = true;
         if (traced2) stamp(a, wave, lane, 16);
         if (traced) stamp(a, wave, lane, 2);
+        if (cp && kCoopFlags && !in_coop) continue;                   // (eight-wavefront builds: the other wavefronts take no part, no barrier to pass)
         if (!cp || leader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's rows have landed (LDS-DMA; a cooperative block: the leader's request)
         if (cp) {
-            asm volatile("s_barrier" ::: "memory");                   // the leaders' rows are in (a bare barrier: see the network barrier above)
-            if (!in_coop) { __syncthreads(); __syncthreads(); continue; }   // (the two barriers of the hand-over below)
+            if (kCoopFlags) {                                         // hand-shake words of group grp: +0 rows in (stretch number), +4 partial sums written (count), +8 sums read (stretch number)
+                if (leader) lds_flag_store(lds, a.lds_flag_offset + 16 * grp, coop_seq);
+                else lds_flag_wait(lds, a.lds_flag_offset + 16 * grp, coop_seq);
+            } else {
+                asm volatile("s_barrier" ::: "memory");               // the leaders' rows are in (a bare barrier: see the network barrier above)
+                if (!in_coop) { __syncthreads(); __syncthreads(); continue; }   // (the two barriers of the hand-over below)
+            }
             rowp = lds + a.lds_weight_bytes + static_cast<size_t>(grp * gsz) * a.lds_wave_bytes + col * RS + 16 * h;   // the leader's staging area
         }
         wave_lds_sync();
@@ -165,12 +171,22 @@
         if (cp) {
             // the hand-over: partial sums of the other members -> the leader, through the members' own staging areas (idle: the stretch
             // is over for them), [register quad][lane] 16 bytes each
+            const int fo = a.lds_flag_offset + 16 * grp;
             if (member != 0) {
                 v4f *pp = reinterpret_cast<v4f *>(ldsw) + lane;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pp[i * 64] = v4f{h1[i >> 2][4 * (i & 3)], h1[i >> 2][4 * (i & 3) + 1], h1[i >> 2][4 * (i & 3) + 2], h1[i >> 2][4 * (i & 3) + 3]};
             }
-            __syncthreads();
+            if (kCoopFlags) {
+                if (member != 0) {
+                    lds_flag_add(lds, fo + 4, 1, lane);                    // (the release fence in front of the add waits for the stores above)
+                    lds_flag_wait(lds, fo + 8, coop_seq);             // the leader has read them: the staging area is this wavefront's again
+                    continue;
+                }
+                lds_flag_wait(lds, fo + 4, gsz - 1);
+            } else {
+                __syncthreads();
+            }
             if (member == 0)
                 for (int m = 1; m < gsz; ++m) {
                     const v4f *qq = reinterpret_cast<const v4f *>(lds + a.lds_weight_bytes + static_cast<size_t>(grp * gsz + m) * a.lds_wave_bytes) + lane;
@@ -181,8 +197,13 @@
                         for (int j = 0; j < 4; ++j) h1[i >> 2][4 * (i & 3) + j] += t[j];
                     }
                 }
-            __syncthreads();                                          // (the members' areas are theirs again)
-            if (member != 0) continue;
+            if (kCoopFlags) {
+                __hip_atomic_store(reinterpret_cast<int *>(lds + fo + 4), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (ready for the next stretch; LDS requests are served in order)
+                lds_flag_store(lds, fo + 8, coop_seq);                // (the release fence waits for the reads above)
+            } else {
+                __syncthreads();                                      // (the members' areas are theirs again)
+                if (member != 0) continue;
+            }
         }
         if (traced) stamp(a, wave, lane, 4);
         if (traced2) stamp(a, wave, lane, 26);

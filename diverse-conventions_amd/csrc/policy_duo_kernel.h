@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const int4 *pre_tile
     // (names and constants the one-block body, included below for single blocks, expects from its kernel)
     constexpr bool CONV_LDS = false, TAIL_LDS = true, FOLD = false;
     constexpr bool gather = false, leader = false, in_coop = false;
-    constexpr int grp = 0, gsz = 0, member = 0, coop_lead = 0;
+    constexpr int grp = 0, gsz = 0, member = 0, coop_lead = 0, coop_seq = 0;
+    constexpr bool kCoopFlags = false;
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;

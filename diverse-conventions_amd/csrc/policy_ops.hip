@@ -116,6 +116,7 @@ struct PolicyArgs {
     int sample;                         // 0: argmax, 1: a draw from the distribution (inverse CDF of one counter-hash uniform per row)
     int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
+    int lds_flag_offset;                // eight-wavefront plans: 64 bytes of hand-shake words behind the staging areas (cooperative blocks by flags), or 0
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
 #ifdef OC_DIAGNOSTICS
     // FOLD builds (diagnostics library only): the env step of slot 0's engine runs inside this launch (see fold_* below)
@@ -174,6 +175,23 @@ __device__ __forceinline__ int prefetch_own_tile(const int4 *pre_tiles, int pre_
     return static_cast<int>(p[0]);                                   // (requested here; keep_prefetched() behind warm_kernarg is its only use)
 }
 __device__ __forceinline__ void keep_prefetched(int v) { asm volatile("" ::"s"(v)); }
+
+// Hand-shake words in LDS between SOME wavefronts of a workgroup (s_barrier takes all of them): a 4-byte LDS word written by one
+// wavefront and polled by others.  LDS requests of a CU are served in order, and an LDS-DMA write has happened when the issuing
+// wavefront's vmcnt has counted it, so whatever the writer finished (and waited for) before the store is there for whoever sees the word.
+__device__ __forceinline__ void lds_flag_store(uint8_t *lds, int off, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(reinterpret_cast<int *>(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_add(uint8_t *lds, int off, int v, int lane) {   // (ONE lane: an LDS atomic adds once per active lane)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<int *>(lds + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_wait(uint8_t *lds, int off, int want) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(reinterpret_cast<int *>(lds + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != want)
+        __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
@@ -716,6 +734,10 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     };
     (void)fold_g; (void)fold_old; (void)fold_exp; (void)fold_n;
 
+    // cooperative blocks by flags (eight-wavefront builds): the hand-shake words start at zero -- written long before their first use,
+    // which lies behind the network barrier every wavefront passes -- and count this workgroup's stretches that share a block
+    int coop_seq = 0;
+    if (CONV_LDS && a.lds_flag_offset && wave == 0 && lane < 16) reinterpret_cast<int *>(lds + a.lds_flag_offset)[lane] = 0;
   for (long long cur = wg0; cur < wg1;) {
     // (read the way policy_find_stretch read it -- scalar for tables mapped to workgroups, vector for a table split evenly -- so that it hits the cache
     // that read filled: the scalar and the vector L1 do not share lines)
@@ -775,10 +797,16 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     // (only in the builds that run one wavefront per SIMD -- conv digits in registers -- and not in the gather build, which is at its
     // register limit without a second block body.  Two wavefronts per SIMD, measured: the barrier in front of the shared block waits
     // for the slowest of eight drifting wavefronts, which costs more than the block -- 52.4 against 48.6 us for the bench line's launch)
-    constexpr bool kCoopBuild = !FOLD && !GATHER && TAIL_LDS && !CONV_LDS;
+    // Eight wavefronts (conv digits in LDS): the same split among wavefronts 0-3 only -- one per SIMD, the ones a stretch's 8 k + 1st / 2nd
+    // block falls to; their SIMD partners 4-7 are a few us behind and take no part -- with LDS hand-shake words instead of the three
+    // barriers (kCoopFlags; round 6: a barrier there waits for the slowest of eight drifting wavefronts, which cost more than the block).
+    constexpr bool kCoopBuild = !FOLD && !GATHER && TAIL_LDS;
+    constexpr bool kCoopFlags = CONV_LDS;
     const int gsz = (!kCoopBuild || !a.coop || rem == 0 || ((flags >> 8) & 0xff) || a.lds_wave_bytes < 8192) ? 0
+                    : kCoopFlags ? ((nwaves != 8 || a.lds_flag_offset == 0) ? 0 : rem == 1 ? 4 : rem == 2 ? 2 : 0)
                     : nwaves != 4 ? 0 : rem == 1 ? 4 : rem == 2 ? 2 : 0;
     const bool coop = gsz > 0 && P >= gsz;
+    coop_seq += coop ? 1 : 0;
     // the leader also runs fc2, head and the epilogue -- about three positions' worth of time -- while the others are already idle:
     // its run of positions is shorter by that much (L + 3 = (P - L) / (g - 1)), one position at least
     const int coop_lead = coop ? min(max((P - kCoopTailPositions * (gsz - 1)) / gsz, 1), P - (gsz - 1)) : 0;
@@ -1287,7 +1315,12 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
         return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: image layout leaves no room for the header behind the LDS tail");
     if (wave_tiles) { waves = 1; a.lds_weight_bytes = 0; }           // one-wavefront workgroups, the whole network in L2 / registers
     while (waves > 1 && a.lds_weight_bytes + static_cast<long long>(waves) * a.lds_wave_bytes > kLds) waves >>= 1;
-    const size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
+    size_t lds = static_cast<size_t>(a.lds_weight_bytes) + static_cast<size_t>(waves) * a.lds_wave_bytes;
+    a.lds_flag_offset = 0;
+    if (waves == 8 && conv_lds && !multi && !wave_tiles && lds + 64 <= static_cast<size_t>(kLds)) {   // hand-shake words of the cooperative blocks (oc_policy_kernel)
+        a.lds_flag_offset = static_cast<int>(lds);
+        lds += 64;
+    }
     if (lds > static_cast<size_t>(kLds))
         return oc_internal_fail(OC_ERR_UNSUPPORTED, "oc_policy_forward: rows of %d bytes do not fit the LDS", a.lds_wave_bytes / kRowsPerBlock);
     typedef void (*kernel_t)(const int4 *, int, const PolicyArgs);

@@ -42,16 +42,19 @@ for name, seg, nseg, rpt in shapes:
     actions = torch.zeros(rows, dtype=torch.int32, device="cuda")
     logp = torch.zeros((rows, 6), device="cuda")
     line = f"{name:36s} {rows:7d} rows {plan.n_tiles:4d} tiles:"
-    for mode in ("0", "1", None):
+    for mode, coop in (("0", "0"), ("0", "1"), ("1", "1"), (None, "1")):
         if mode is None:
             os.environ.pop("OC_POLICY_DUO", None)
         else:
             os.environ["OC_POLICY_DUO"] = mode
+        os.environ["OC_POLICY_COOP"] = coop
         best, med = timed(lambda: plan.forward(obs, actions=actions, logp=logp, deterministic=True))
-        line += f"  {'default' if mode is None else 'duo=' + mode} {best:6.2f} / {med:6.2f}"
+        line += f"  {'default' if mode is None else 'duo=' + mode + (' no coop' if coop == '0' else '')} {best:6.2f} / {med:6.2f}"
         a, l = actions.clone(), logp.clone()
-        if mode == "0":
+        if name not in ref:
             ref[name] = (a, l)
         else:
-            assert torch.equal(a, ref[name][0]) and torch.equal(l, ref[name][1]), "the kernels disagree"
+            # (bit for bit unless the one-block kernel shared a stretch's last blocks among wavefronts: those sum fc1 in another order)
+            d = (l - ref[name][1]).abs().max().item()
+            assert d < 4e-6 and (a != ref[name][0]).float().mean().item() < 1e-4, f"the kernels disagree: {d}"
     print(line + "  us (best / median of 7 x 100 launches)", flush=True)
