@@ -287,11 +287,11 @@
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = 4 * h + r < n_out ? out[r] : -INFINITY;
             float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, xor32(mx, h != 0));
             float ex[4], own = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ex[r] = __expf(x[r] - mx); own += ex[r]; }
-            const float other = __shfl_xor(own, 32);
+            const float other = xor32(own, h != 0);
             const float sum = own + other;
             const float lse = mx + __logf(sum);
             float lps[4];
@@ -309,16 +309,17 @@
                 float c = h ? other : 0.f, cum[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { c += ex[r]; cum[r] = c; }
-                const float thr = u * __shfl(c, lane | 32);
+                const float c_other = xor32(c, h != 0);                    // (every lane takes part in the exchange)
+            const float thr = u * (h ? c : c_other);
                 int cnt = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cnt += cum[r] <= thr ? 1 : 0;
-                best = min(cnt + __shfl_xor(cnt, 32), n_out - 1);
+                best = min(cnt + xor32(cnt, h != 0), n_out - 1);
                 const int local = best - 4 * h;
                 float lp_sel = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) lp_sel = local == r ? lps[r] : lp_sel;
-                best_lp = lp_sel + __shfl_xor(lp_sel, 32);
+                best_lp = lp_sel + xor32(lp_sel, h != 0);
             } else {
                 float best_key = -INFINITY;
 #pragma unroll
@@ -326,8 +327,8 @@
                     const bool wins = lps[r] > best_key;
                     best_key = wins ? lps[r] : best_key; best = wins ? 4 * h + r : best; best_lp = wins ? lps[r] : best_lp;
                 }
-                const float okey = __shfl_xor(best_key, 32), olp = __shfl_xor(best_lp, 32);
-                const int obest = __shfl_xor(best, 32);
+                const float okey = xor32(best_key, h != 0), olp = xor32(best_lp, h != 0);
+                const int obest = xor32(best, h != 0);
                 if (okey > best_key || (okey == best_key && obest < best)) { best = obest; best_lp = olp; }
             }
             if (valid && h == 0) {

@@ -193,6 +193,17 @@ __device__ __forceinline__ void lds_flag_wait(uint8_t *lds, int off, int want) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The value the lane 32 places away holds (__shfl_xor(x, 32)): v_permlane32_swap exchanges the upper half of one register with the
+// lower half of another -- a vector instruction and a select where ds_bpermute_b32 is an LDS round trip (~100 cycles on the epilogue's
+// dependent chain: maximum -> sum -> chosen action, tools/probes/permlane32_swap.hip).  `upper`: lane >= 32.
+__device__ __forceinline__ unsigned xor32_bits(unsigned u, bool upper) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r.x = {lower, lower}, r.y = {upper, upper}
+    return upper ? r.x : r.y;
+}
+__device__ __forceinline__ float xor32(float x, bool upper) { return __builtin_bit_cast(float, xor32_bits(__builtin_bit_cast(unsigned, x), upper)); }
+__device__ __forceinline__ int xor32(int x, bool upper) { return static_cast<int>(xor32_bits(static_cast<unsigned>(x), upper)); }
+
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
     // accesses across the hand-over between "stage rows" and "read fragments"
