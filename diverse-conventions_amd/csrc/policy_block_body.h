@@ -63,15 +63,6 @@
         const int coop_rest = P - coop_lead, coop_each = cp ? coop_rest / (gsz - 1) : 0, coop_more = cp ? coop_rest - coop_each * (gsz - 1) : 0;
         const int p_first = !cp ? 0 : member == 0 ? 0 : coop_lead + (member - 1) * coop_each + min(member - 1, coop_more);
         const int p_end = !cp ? P : member == 0 ? coop_lead : p_first + coop_each + (member - 1 < coop_more ? 1 : 0);
-        int pi = 0, xq = 0, yq = 0;                                   // position whose B operands `bfr` holds
-        auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
-        for (int i = 0; i < p_first; ++i) advance();
-        v4i bfr[6];
-        read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
-        v16i acc[NDIG];
-        conv(acc, bfr);                                               // the first position
-        advance();
-        read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
         v16f h1[2];                                                   // accumulators start at the bias (a cooperative block: the leader's do)
         {
             const v4f *bq = reinterpret_cast<const v4f *>(b1);
@@ -81,7 +72,6 @@
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h1[m][r] = with_bias ? bq[m * 8 + (r >> 2)][r & 3] : 0.f;
         }
-        if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
         // wave tiles: the dense layers' biases come from L2 -- requested here, used after the position loop
         v4f b2q[TAIL_LDS ? 1 : 8], bhq = {0.f, 0.f, 0.f, 0.f};
         if (!TAIL_LDS) {
@@ -89,19 +79,6 @@
             for (int i = 0; i < 8; ++i) b2q[TAIL_LDS ? 0 : i] = reinterpret_cast<const v4f *>(b2)[(i >> 2) * 8 + (i & 3)];
             bhq = *reinterpret_cast<const v4f *>(bh);
         }
-        // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
-        auto make_operand = [&](v4i (&dst)[kPieces][2], int j) {      // pair j = accumulator registers 2j, 2j + 1
-            int hi, lo;
-            float x0, x1;
-            combine_pair(acc, 2 * j, x0, x1);
-            split_pair(x0, x1, hi, lo);
-            dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = lo;
-        };
-        v4i xb[kPieces][2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) make_operand(xb, j);
-        if (traced2) stamp(a, wave, lane, 19);
-
         // fc1 fragments of a position [piece][k-group][out half].  They are requested one position ahead, into the registers
         // the MFMAs of the current position have just read, so an L2 round trip (fc1 not LDS-resident) has the operand
         // conversion and the next conv to land in.
@@ -116,57 +93,93 @@
                         w1r[q][g][mo] = FC1_LDS ? w1l[(p * (4 * kPieces) + (q * 2 + g) * 2 + mo) * 64]
                                                 : w1_from_l2(w1g, lane16, p, (q * 2 + g) * 2 + mo);
         };
-        load_w1(p_first);
-        // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x three piece products x two
-        // output halves.  Unless it is the last, the next position's operand is built around them: the second k-group's
-        // registers (pairs 4..7) into spare registers next to the first group's MFMAs, the first group's (pairs 0..3) in place
-        // once its MFMAs have issued.
-        auto position = [&](int p, auto last_tag) {
-            constexpr bool kLast = decltype(last_tag)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if (!kLast) conv(acc, bfr);                               // conv of position p+1
-            __builtin_amdgcn_sched_barrier(0);
-            if (!kLast) {
-                advance();
-                read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);    // position p+2
+        // One wavefront per SIMD (conv digits in registers): the position loop pipelined inside the wavefront -- conv(p+1) and fc1(p-1)
+        // beside the conversion of position p, on two sets of conv accumulators (policy_mono_loop.h); same instructions on the same
+        // values in the same accumulation order as the loop below: bit-identical outputs.  (Cooperative blocks keep the loop below:
+        // their members run a few positions each.)
+        bool use_mono = false;
+        if constexpr (kMono && !cp) {
+            use_mono = a.mono != 0;
+            if (use_mono) {
+#include "policy_mono_loop.h"
             }
-            __builtin_amdgcn_sched_barrier(0);
-            v4i nb1[kPieces];
+        }
+        if (!use_mono) {
+            int pi = 0, xq = 0, yq = 0;                                   // position whose B operands `bfr` holds
+            auto advance = [&]() { if (pi + 1 < P) { ++pi; if (++yq == PH) { yq = 0; ++xq; } } };   // (clamped: re-reads the last)
+            for (int i = 0; i < p_first; ++i) advance();
+            v4i bfr[6];
+            read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
+            v16i acc[NDIG];
+            conv(acc, bfr);                                               // the first position
+            advance();
+            read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);
+            if (traced2) stamp(a, wave, lane, 18);                         // conv of position 0 issued, next fragments requested
+            // fc1 operand of a position: pieces [piece][k-group] of its 16 conv outputs, built pair by pair
+            auto make_operand = [&](v4i (&dst)[kPieces][2], int j) {      // pair j = accumulator registers 2j, 2j + 1
+                int hi, lo;
+                float x0, x1;
+                combine_pair(acc, 2 * j, x0, x1);
+                split_pair(x0, x1, hi, lo);
+                dst[0][j >> 2][j & 3] = hi; dst[1][j >> 2][j & 3] = lo;
+            };
+            v4i xb[kPieces][2];
 #pragma unroll
-            for (int t = 0; t < kTerms; ++t) {
-                h1[0] = mfma_f16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
-                h1[1] = mfma_f16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
-                if (!kLast) {                                          // pairs 4..7 of the next operand, spread over the three terms: 2, 1, 1
+            for (int j = 0; j < 8; ++j) make_operand(xb, j);
+            if (traced2) stamp(a, wave, lane, 19);
+
+            load_w1(p_first);
+            // fc1 partial of position p: h1^T[n][row] += W1[n][o*P + p] * X^T[o][row]: two k-groups x three piece products x two
+            // output halves.  Unless it is the last, the next position's operand is built around them: the second k-group's
+            // registers (pairs 4..7) into spare registers next to the first group's MFMAs, the first group's (pairs 0..3) in place
+            // once its MFMAs have issued.
+            auto position = [&](int p, auto last_tag) {
+                constexpr bool kLast = decltype(last_tag)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if (!kLast) conv(acc, bfr);                               // conv of position p+1
+                __builtin_amdgcn_sched_barrier(0);
+                if (!kLast) {
+                    advance();
+                    read_bfrags(rowp, __builtin_amdgcn_readfirstlane((xq * H + yq) * OC_POLICY_C), colstep, bfr);    // position p+2
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v4i nb1[kPieces];
 #pragma unroll
-                    for (int u = (t == 0 ? 0 : t + 1); u < (t == 0 ? 2 : t + 2); ++u) {
-                        int hi, lo;
-                        float x0, x1;
-                        combine_pair(acc, 8 + 2 * u, x0, x1);
-                        split_pair(x0, x1, hi, lo);
-                        nb1[0][u] = hi; nb1[1][u] = lo;
+                for (int t = 0; t < kTerms; ++t) {
+                    h1[0] = mfma_f16(w1r[kTermW[t]][0][0], xb[kTermX[t]][0], h1[0]);
+                    h1[1] = mfma_f16(w1r[kTermW[t]][0][1], xb[kTermX[t]][0], h1[1]);
+                    if (!kLast) {                                          // pairs 4..7 of the next operand, spread over the three terms: 2, 1, 1
+#pragma unroll
+                        for (int u = (t == 0 ? 0 : t + 1); u < (t == 0 ? 2 : t + 2); ++u) {
+                            int hi, lo;
+                            float x0, x1;
+                            combine_pair(acc, 8 + 2 * u, x0, x1);
+                            split_pair(x0, x1, hi, lo);
+                            nb1[0][u] = hi; nb1[1][u] = lo;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int t = 0; t < kTerms; ++t) {
-                h1[0] = mfma_f16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
-                h1[1] = mfma_f16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
-            }
-            if (!kLast) {
-                __builtin_amdgcn_sched_barrier(0);
-                load_w1(p + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < kTerms; ++t) {
+                    h1[0] = mfma_f16(w1r[kTermW[t]][1][0], xb[kTermX[t]][1], h1[0]);
+                    h1[1] = mfma_f16(w1r[kTermW[t]][1][1], xb[kTermX[t]][1], h1[1]);
+                }
+                if (!kLast) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w1(p + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) make_operand(xb, t);
+                    for (int t = 0; t < 4; ++t) make_operand(xb, t);
 #pragma unroll
-                for (int q = 0; q < kPieces; ++q) xb[q][1] = nb1[q];
+                    for (int q = 0; q < kPieces; ++q) xb[q][1] = nb1[q];
+                }
+                if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
+            };
+            {
+                int p = p_first;
+                for (; p + 1 < p_end; ++p) position(p, std::false_type());
+                position(p, std::true_type());
             }
-            if (traced2 && p < 6) stamp(a, wave, lane, 20 + p);
-        };
-        {
-            int p = p_first;
-            for (; p + 1 < p_end; ++p) position(p, std::false_type());
-            position(p, std::true_type());
         }
         if (cp) {
             // the hand-over: partial sums of the other members -> the leader, through the members' own staging areas (idle: the stretch

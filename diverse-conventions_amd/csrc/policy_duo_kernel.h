@@ -30,11 +30,6 @@
 // The interleave of a half-step, pinned for the scheduler: N times [one matrix instruction, then the vector instructions that run
 // under it], an LDS read added from the FIRST_DS-th gap on (masks: 0x008 MFMA, 0x002 VALU, 0x100 LDS read).  The counts are upper
 // bounds -- a group takes what is there -- and the builtin wants literal constants, hence the recursion.
-// f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>), in order: compile-time indices into register arrays
-template <int... Is, class F>
-__device__ __forceinline__ void oc_static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>()), ...); }
-template <int N, class F>
-__device__ __forceinline__ void oc_static_for(F &&f) { oc_static_for_impl(std::make_integer_sequence<int, N>(), static_cast<F &&>(f)); }
 
 template <int N, int FIRST_DS, int I = 0>
 __device__ __forceinline__ void oc_pin_interleave() {
@@ -53,7 +48,7 @@ __global__ __launch_bounds__(256) void oc_policy_duo_kernel(const int4 *pre_tile
     constexpr bool CONV_LDS = false, TAIL_LDS = true, FOLD = false;
     constexpr bool gather = false, leader = false, in_coop = false;
     constexpr int grp = 0, gsz = 0, member = 0, coop_lead = 0, coop_seq = 0;
-    constexpr bool kCoopFlags = false;
+    constexpr bool kCoopFlags = false, kMono = false;                 // (single blocks here run the plain loop of policy_block_body.h)
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;

@@ -116,6 +116,7 @@ struct PolicyArgs {
     int sample;                         // 0: argmax, 1: a draw from the distribution (inverse CDF of one counter-hash uniform per row)
     int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
+    int mono;                           // one-wavefront-per-SIMD builds: the position loop pipelined inside the wavefront (policy_mono_loop.h); 0: the plain loop (OC_POLICY_MONO=0)
     int lds_flag_offset;                // eight-wavefront plans: 64 bytes of hand-shake words behind the staging areas (cooperative blocks by flags), or 0
     unsigned long long *trace;          // diagnostics (oc_policy_debug_trace): [workgroup*8 + wave][32] stamps, or NULL
 #ifdef OC_DIAGNOSTICS
@@ -203,6 +204,12 @@ __device__ __forceinline__ unsigned xor32_bits(unsigned u, bool upper) {
 }
 __device__ __forceinline__ float xor32(float x, bool upper) { return __builtin_bit_cast(float, xor32_bits(__builtin_bit_cast(unsigned, x), upper)); }
 __device__ __forceinline__ int xor32(int x, bool upper) { return static_cast<int>(xor32_bits(static_cast<unsigned>(x), upper)); }
+
+// f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>), in order: compile-time indices into register arrays
+template <int... Is, class F>
+__device__ __forceinline__ void oc_static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>()), ...); }
+template <int N, class F>
+__device__ __forceinline__ void oc_static_for(F &&f) { oc_static_for_impl(std::make_integer_sequence<int, N>(), static_cast<F &&>(f)); }
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wavefront executes in program order; this only stops the compiler from moving LDS
@@ -632,6 +639,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     // the loaded network's descale factors (powers of two, policy_pack.h): fc1 accumulators -> fc2 operand, fc2 -> head operand, head -> outputs
     float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     bool trace_done = false, trace2_done = false;
+    constexpr bool kMono = !CONV_LDS && !FOLD;                        // see policy_mono_loop.h
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     // conv result -> fc1 operand: relu(2^-shift x f32(sum of digit accumulators)), two accumulator registers at a time.  The channel's
@@ -1446,6 +1454,8 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     a.desync = env_desync ? atoi(env_desync) : 0;
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
     a.coop = env_coop ? atoi(env_coop) != 0 : 1;
+    const char *const env_mono = getenv("OC_POLICY_MONO");           // (read per call) 0 = the plain position loop in the one-wavefront-per-SIMD builds: A/B runs
+    a.mono = env_mono ? atoi(env_mono) != 0 : 1;
     int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
     static const char *const env_grid = OC_DIAG_ENV("OC_POLICY_GRID");
     if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }

@@ -25,7 +25,7 @@ LIB_OVERRIDE = os.environ.get("OC_LIB_PATH", "")
 LIB_PATH = LIB_OVERRIDE or os.path.join(CSRC, "liboc_hip_asan.so" if SANITIZE else "liboc_hip_diag.so" if DIAGNOSTICS else "liboc_hip.so")
 SOURCES = [os.path.join(CSRC, "overcooked_engine.hip"), os.path.join(CSRC, "rollout_ops.hip"),
            os.path.join(CSRC, "policy_ops.hip")]
-HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h"), os.path.join(CSRC, "policy_block_body.h"),
+HEADERS = [os.path.join(CSRC, "policy_pack.h"), os.path.join(CSRC, "oc_internal.h"), os.path.join(CSRC, "policy_block_body.h"), os.path.join(CSRC, "policy_mono_loop.h"),
            os.path.join(CSRC, "policy_duo_kernel.h"), os.path.join(CSRC, "policy_duo_body.h"),
            os.path.join(CSRC, "oc_np_kernels.h")]
 KERNEL_HEADER = os.path.join(CSRC, "oc_step_kernel.h")              # ahead-of-time (generic) build

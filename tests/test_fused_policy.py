@@ -357,6 +357,40 @@ def test_cooperative_blocks(W, H, blocks, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("W,H,digits", [(9, 5, 3), (8, 5, 3), (5, 5, 3), (3, 3, 3), (4, 3, 3), (5, 3, 3), (9, 5, 4), (8, 5, 2), (5, 5, 1)])
+def test_pipelined_position_loop_equals_the_plain_loop(W, H, digits, monkeypatch):
+    """Builds with one wavefront per SIMD (every grid but 5x4) run the position loop pipelined inside the wavefront (policy_mono_loop.h,
+    round 6): conv(p+1) and fc1(p-1) beside the conversion of position p, on two sets of conv accumulators.  The same instructions on
+    the same values in the same accumulation order as the plain loop (OC_POLICY_MONO=0): BIT for bit, for odd and even numbers of conv
+    positions down to one and two (3x3, 4x3), every digit count, ragged last blocks, actors (argmax and sampled) and critics; and
+    against the numpy restatement of the reference's f32 forward."""
+    from oracle.policy_oracle import log_softmax, reference_forward
+    monkeypatch.setenv("OC_POLICY_COOP", "0")
+    monkeypatch.setenv("OC_POLICY_DUO", "0")
+    actor, critic = random_net(W, H, 6, ACTOR_HEAD, 31), random_net(W, H, 1, CRITIC_HEAD, 32)
+    nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[actor], critics=[critic], digits=digits)
+    rng = np.random.default_rng(W * 100 + H * 10 + digits)
+    n = 128 * 3 * 32 - 11                                           # 128 workgroups x three blocks, the very last one ragged
+    obs_np = (rng.random((n, W, H, 20)) < 0.15).astype(np.int8) * rng.integers(1, 21, size=(n, W, H, 20), dtype=np.int8)
+    obs = torch.from_numpy(obs_np).cuda()
+    got = {}
+    for mono in ("1", "0"):
+        monkeypatch.setenv("OC_POLICY_MONO", mono)
+        a = _run(nets, n, [(0, n, 0, TILE_ACT)], obs, rows_per_tile=96, deterministic=True)
+        smp = _run(nets, n, [(0, n, 0, TILE_ACT)], obs, rows_per_tile=96, deterministic=False, seed=7, counter=3)
+        v = _run(nets, n, [(0, n, 1, 0)], obs, rows_per_tile=96)["raw"].reshape(-1)[:n]
+        got[mono] = (a, smp, v)
+    (a1, s1, v1), (a0, s0, v0) = got["1"], got["0"]
+    assert np.array_equal(a1["logp"], a0["logp"]) and np.array_equal(a1["actions"], a0["actions"]) and np.array_equal(a1["action_logp"], a0["action_logp"])
+    assert np.array_equal(s1["actions"], s0["actions"]) and np.array_equal(s1["action_logp"], s0["action_logp"]) and np.array_equal(v1, v0)
+    want_lp = log_softmax(reference_forward(actor, obs_np, ACTOR_HEAD))
+    want_v = reference_forward(critic, obs_np, CRITIC_HEAD).reshape(-1)
+    scale = max(1.0, float(np.abs(want_lp).max()), float(np.abs(want_v).max()))
+    tol = {1: 2e-2, 2: 2e-4, 3: 4e-6, 4: 4e-6}[digits] * scale      # (one / two conv digits: 8- / 16-bit conv weights)
+    assert np.abs(a1["logp"] - want_lp).max() < tol and np.abs(v1 - want_v).max() < tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("W,H", [(5, 4), (5, 5), (3, 3)])
 def test_two_blocks_per_wavefront_equal_the_one_block_kernel(W, H, monkeypatch):
     """oc_policy_duo_kernel (round 6: one wavefront per SIMD interleaving TWO 32-row blocks, policy_duo_kernel.h / policy_duo_body.h)
@@ -448,6 +482,40 @@ def test_multi_grid_launch_equals_per_grid_launches(monkeypatch):
             for key in ("raw", "actions", "action_logp", "logp"):
                 assert torch.equal(got[i][key], want[i][key]), (i, key, plan.tiles_per_workgroup)
             assert int((got[i]["actions"] < 0).sum()) == 0 and not bool(torch.isnan(got[i]["raw"]).any())
+
+
+@pytest.mark.gpu
+def test_pipelined_position_loop_on_one_two_and_three_positions(monkeypatch):
+    """Grids of 3x3, 4x3 and 5x3 tiles (one, two, three conv positions) through a multi-grid launch -- four-wavefront workgroups, conv
+    digits in registers: the pipelined position loop's shortest cases (policy_mono_loop.h: no step at all, a last step only, one full
+    step) -- against the per-grid launches, which run these small grids on the eight-wavefront build and its plain loop: bit for bit."""
+    monkeypatch.setenv("OC_POLICY_COOP", "0")
+    from diverse_conventions_amd.fused_policy import MultiPolicyPlan
+    rng = np.random.default_rng(77)
+    grids, rows = [(3, 3), (4, 3), (5, 3)], [700, 333, 1029]
+    nets, segs, obs = [], [], []
+    for (W, H), n in zip(grids, rows):
+        nets.append(PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=[random_net(W, H, 6, ACTOR_HEAD, 300 + W * H)],
+                                                    critics=[random_net(W, H, 1, CRITIC_HEAD, 400 + W * H)]))
+        segs.append([(0, n, 0, TILE_ACT), (0, n, 1, 0)])
+        obs.append(torch.from_numpy(((rng.random((n, W, H, 20)) < 0.15) * rng.integers(1, 21, (n, W, H, 20))).astype(np.int8)).cuda())
+    new = lambda n, w, dt, fill: torch.full((n, w) if w else (n,), fill, dtype=dt, device="cuda")
+    mk = lambda n: dict(raw=new(n, 0, torch.float32, float("nan")), actions=new(n, 0, torch.int32, -1), action_logp=new(n, 0, torch.float32, float("nan")),
+                        logp=new(n, 6, torch.float32, float("nan")))
+    want = []
+    for i, n in enumerate(rows):
+        o = mk(n)
+        PolicyPlan(nets[i], n, segs[i]).forward(obs[i], seed=9, counter=2, **o)
+        want.append(o)
+    for mono in ("1", "0"):
+        monkeypatch.setenv("OC_POLICY_MONO", mono)
+        got = [mk(n) for n in rows]
+        MultiPolicyPlan(nets, rows, segs).forward(obs, raw=[g["raw"] for g in got], actions=[g["actions"] for g in got],
+                                                  action_logp=[g["action_logp"] for g in got], logp=[g["logp"] for g in got], seeds=[9, 9, 9], counter=2)
+        torch.cuda.synchronize()
+        for i in range(3):
+            for key in ("raw", "actions", "action_logp", "logp"):
+                assert torch.equal(got[i][key], want[i][key]), (mono, i, key)
 
 
 @pytest.mark.gpu

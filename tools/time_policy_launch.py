@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""hipEvent time of ONE fused policy launch (product library) at the shapes the round's targets are quoted on, one-block kernel
-(OC_POLICY_DUO=0) against the two-blocks-per-wavefront kernel (=1) and the default choice; best and median of several batches.
+"""hipEvent time of ONE fused policy launch (product library) at the shapes the round's targets are quoted on: the one-block kernel with
+its plain position loop (OC_POLICY_MONO=0; only differs where one wavefront runs per SIMD: every grid but 5x4), without shared blocks
+(OC_POLICY_COOP=0), as it is, the two-blocks-per-wavefront kernel (OC_POLICY_DUO=1) and the default choice; best and median of several batches.
 
     python tools/time_policy_launch.py [W H]"""
 import os, sys
@@ -42,19 +43,21 @@ for name, seg, nseg, rpt in shapes:
     actions = torch.zeros(rows, dtype=torch.int32, device="cuda")
     logp = torch.zeros((rows, 6), device="cuda")
     line = f"{name:36s} {rows:7d} rows {plan.n_tiles:4d} tiles:"
-    for mode, coop in (("0", "0"), ("0", "1"), ("1", "1"), (None, "1")):
-        if mode is None:
-            os.environ.pop("OC_POLICY_DUO", None)
-        else:
-            os.environ["OC_POLICY_DUO"] = mode
-        os.environ["OC_POLICY_COOP"] = coop
+    modes = [("one block, plain loop, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_MONO": "0", "OC_POLICY_COOP": "0"}), ("one block, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "0"}),
+             ("one block", {"OC_POLICY_DUO": "0"}), ("duo", {"OC_POLICY_DUO": "1"}), ("default", {})]
+    for label, env in modes:
+        for k in ("OC_POLICY_DUO", "OC_POLICY_COOP", "OC_POLICY_MONO"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
         best, med = timed(lambda: plan.forward(obs, actions=actions, logp=logp, deterministic=True))
-        line += f"  {'default' if mode is None else 'duo=' + mode + (' no coop' if coop == '0' else '')} {best:6.2f} / {med:6.2f}"
+        line += f"  {label} {best:6.2f} / {med:6.2f}"
         a, l = actions.clone(), logp.clone()
         if name not in ref:
             ref[name] = (a, l)
         else:
             # (bit for bit unless the one-block kernel shared a stretch's last blocks among wavefronts: those sum fc1 in another order)
+            if label == "one block, no coop":                       # (the pipelined position loop: the same instructions in the same order)
+                assert torch.equal(a, ref[name][0]) and torch.equal(l, ref[name][1]), "the pipelined position loop is not bit-identical"
             d = (l - ref[name][1]).abs().max().item()
             assert d < 4e-6 and (a != ref[name][0]).float().mean().item() < 1e-4, f"the kernels disagree: {d}"
     print(line + "  us (best / median of 7 x 100 launches)", flush=True)
