@@ -124,7 +124,7 @@
                     if constexpr (!kLast && i >= kConvM && ((i - kConvM) & 1) == 0 && (i - kConvM) / 2 < 6) read_b6(Xc, std::integral_constant<int, (i - kConvM) / 2>());
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                load_w1_set(Xc, min(p + 1, P - 1));                   // X's buffer: the fragments of fc1(p + 1), its next
+                load_w1_set(Xc, a.mono == 2 ? 0 : min(p + 1, P - 1));   // X's buffer: the fragments of fc1(p + 1), its next  (OC_POLICY_MONO=2, timing only -- wrong outputs: position 0's again, from the vector L1)
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto fc1_all = [&](auto Sc) { oc_static_for<kFc1M>([&](auto Ic) { fc1_i(Sc, Ic); }); };

@@ -1455,7 +1455,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
     a.coop = env_coop ? atoi(env_coop) != 0 : 1;
     const char *const env_mono = getenv("OC_POLICY_MONO");           // (read per call) 0 = the plain position loop in the one-wavefront-per-SIMD builds: A/B runs
-    a.mono = env_mono ? atoi(env_mono) != 0 : 1;
+    a.mono = env_mono ? atoi(env_mono) : 1;
     int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
     static const char *const env_grid = OC_DIAG_ENV("OC_POLICY_GRID");
     if (env_grid) { const int g = atoi(env_grid); if (g >= 1 && g <= 65535 && !a.tile_per_wg) grid = g; }
