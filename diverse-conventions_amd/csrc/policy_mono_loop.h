@@ -21,8 +21,8 @@
             // a set's position counters: the position whose B fragments it reads next, its row inside the grid column and its byte offset in
             // a staged row -- wave-uniform, and pinned to scalar registers (readfirstlane: left to itself the compiler computed them per lane,
             // ~35 vector instructions per step in one MFMA gap)
-            int mq[2] = {0, 0}, myq[2] = {0, 0}, moff[2] = {0, 0};
-            v4i bfr2[2][6];
+            int mq = 0, myq = 0, moff = 0;
+            v4i bfr1[6];                                              // ONE set of B fragments: the next conv's, read behind the fc1 MFMAs of the step before
             v16i acc2[2][NDIG];
             v4i xb2[2][kPieces][2];
             // fc1 fragments [set][piece][k-group][out half]: a set's buffer is refilled with the fragments of position p + 1 right behind the
@@ -41,23 +41,21 @@
                                                         : w1_from_l2(w1g, lane16, p, (q * 2 + g) * 2 + mo);
             };
             const int col_wrap = colstep - (PH - 1) * OC_POLICY_C;        // from the last position of a column to the first of the next
-            auto adv1 = [&](auto Sc) {                                // (clamped: re-reads the last; branch-free)
-                constexpr int s = decltype(Sc)::value;
-                const int inc = mq[s] + 1 < P ? 1 : 0;
-                const int y = myq[s] + inc, wrap = y == PH ? 1 : 0;
-                mq[s] = __builtin_amdgcn_readfirstlane(mq[s] + inc);
-                myq[s] = __builtin_amdgcn_readfirstlane(wrap ? 0 : y);
-                moff[s] = __builtin_amdgcn_readfirstlane(moff[s] + (inc ? (wrap ? col_wrap : OC_POLICY_C) : 0));
+            auto adv1 = [&]() {                                       // (clamped: re-reads the last; branch-free)
+                const int inc = mq + 1 < P ? 1 : 0;
+                const int y = myq + inc, wrap = y == PH ? 1 : 0;
+                mq = __builtin_amdgcn_readfirstlane(mq + inc);
+                myq = __builtin_amdgcn_readfirstlane(wrap ? 0 : y);
+                moff = __builtin_amdgcn_readfirstlane(moff + (inc ? (wrap ? col_wrap : OC_POLICY_C) : 0));
             };
-            auto adv2 = [&](auto Sc) { adv1(Sc); adv1(Sc); };
-            auto read_b6 = [&](auto Sc, auto Kc) {                    // one sixth of a set's B fragments (kernel column kx = k >> 1, half k & 1)
-                constexpr int s = decltype(Sc)::value, k = decltype(Kc)::value;
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + (moff[s] + (k >> 1) * colstep + 32 * (k & 1)));
+            auto read_b6 = [&](auto Kc) {                             // one sixth of a position's B fragments (kernel column kx = k >> 1, half k & 1)
+                constexpr int k = decltype(Kc)::value;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(rowp + (moff + (k >> 1) * colstep + 32 * (k & 1)));
                 v4i v;
                 v.x = static_cast<int>(q[0]); v.y = static_cast<int>(q[1]); v.z = static_cast<int>(q[2]); v.w = static_cast<int>(q[3]);
-                bfr2[s][k] = v;
+                bfr1[k] = v;
             };
-            auto read_b_all = [&](auto Sc) { oc_static_for<6>([&](auto Kc) { read_b6(Sc, Kc); }); };
+            auto read_b_all = [&]() { oc_static_for<6>([&](auto Kc) { read_b6(Kc); }); };
             // the conversion of a set's conv sums as 128 single-instruction micro-steps (policy_duo_body.h: convert_u)
             float cv_t[8][2], cv_u[8][2];                              // (one set converts at a time: shared)
             v2h cv_h[8];
@@ -104,7 +102,7 @@
                         for (int r = 0; r < 16; ++r) acc2[b][d][r] = 0;
                     }
                 }
-                acc2[b][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[ks][d], bfr2[b][ks], acc2[b][d], 0, 0, 0);
+                acc2[b][d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wA[ks][d], bfr1[ks], acc2[b][d], 0, 0, 0);
             };
             auto fc1_i = [&](auto Sc, auto Ic) {                      // fc1 MFMA i of 4 x kTerms, in the order of the loop below: k-group, term, output half
                 constexpr int b = decltype(Sc)::value, i = decltype(Ic)::value, m = i & 1, t = (i >> 1) % kTerms, g = (i >> 1) / kTerms;
@@ -114,14 +112,14 @@
             auto step = [&](auto Xc, auto Yc, auto last_tag, int p) {
                 constexpr bool kLast = decltype(last_tag)::value;
                 constexpr int nM = (kLast ? 0 : kConvM) + kFc1M;
-                if constexpr (!kLast) adv2(Xc);                       // (X's counters: the position whose fragments are read during this step)
+                if constexpr (!kLast) adv1();                         // (the position whose fragments are read during this step: p + 2, the next step's conv)
                 oc_static_for<nM>([&](auto Ic) {
                     constexpr int i = decltype(Ic)::value;
                     if constexpr (!kLast && i < kConvM) conv_i(Xc, Ic);
                     else fc1_i(Xc, std::integral_constant<int, i - (kLast ? 0 : kConvM)>());
                     oc_static_for<(kCvtSteps * (i + 1)) / nM - (kCvtSteps * i) / nM>([&](auto Sc) { convert_u(Yc, std::integral_constant<int, (kCvtSteps * i) / nM + decltype(Sc)::value>()); });
-                    // X's B fragments of the position after next: one sixth behind every second fc1 MFMA (their registers are free: X's conv has issued)
-                    if constexpr (!kLast && i >= kConvM && ((i - kConvM) & 1) == 0 && (i - kConvM) / 2 < 6) read_b6(Xc, std::integral_constant<int, (i - kConvM) / 2>());
+                    // the next step's B fragments: one sixth behind every second fc1 MFMA (the registers are free: this step's conv has issued)
+                    if constexpr (!kLast && i >= kConvM && ((i - kConvM) & 1) == 0 && (i - kConvM) / 2 < 6) read_b6(std::integral_constant<int, (i - kConvM) / 2>());
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 load_w1_set(Xc, a.mono == 2 ? 0 : min(p + 1, P - 1));   // X's buffer: the fragments of fc1(p + 1), its next  (OC_POLICY_MONO=2, timing only -- wrong outputs: position 0's again, from the vector L1)
@@ -129,14 +127,12 @@
             };
             auto fc1_all = [&](auto Sc) { oc_static_for<kFc1M>([&](auto Ic) { fc1_i(Sc, Ic); }); };
 
-            read_b_all(SetA());                                       // position 0
-            adv1(SetB());
-            read_b_all(SetB());                                       // position 1 (P = 1: position 0 again, never used)
+            read_b_all();                                             // position 0
             load_w1_set(SetA(), 0);
             load_w1_set(SetB(), min(1, P - 1));
             oc_static_for<kConvM>([&](auto Ic) { conv_i(SetA(), Ic); });     // conv(0)
-            adv2(SetA());
-            read_b_all(SetA());                                       // position 2
+            adv1();
+            read_b_all();                                             // position 1 (P = 1: position 0 again, never used)
             __builtin_amdgcn_sched_barrier(0);
             if (traced2) stamp(a, wave, lane, 18);
             if (P == 1) {
@@ -150,8 +146,8 @@
                     oc_static_for<(kCvtSteps * (i + 1)) / kConvM - (kCvtSteps * i) / kConvM>([&](auto Sc) { convert_u(SetA(), std::integral_constant<int, (kCvtSteps * i) / kConvM + decltype(Sc)::value>()); });
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                adv2(SetB());
-                read_b_all(SetB());                                   // position 3
+                adv1();
+                read_b_all();                                         // position 2
                 __builtin_amdgcn_sched_barrier(0);
                 if (traced2) stamp(a, wave, lane, 19);
                 int p = 1;

@@ -639,7 +639,15 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     // the loaded network's descale factors (powers of two, policy_pack.h): fc1 accumulators -> fc2 operand, fc2 -> head operand, head -> outputs
     float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     bool trace_done = false, trace2_done = false;
-    constexpr bool kMono = !CONV_LDS && !FOLD;                        // see policy_mono_loop.h
+    // The position loop pipelined inside the wavefront (policy_mono_loop.h), for the builds that run one wavefront per SIMD: built, bit-identical,
+    // 5-7 % faster on large 9x5 launches -- and compiled into the DIAGNOSTICS library only (or with -DOC_POLICY_MONO_LOOP): at three conv
+    // digits its two accumulator sets push the kernel past 512 registers, the spills land in scratch, and their reloads behind every block
+    // cost config 4's per-GPU share (one block per wavefront) 7 us of 39 per step whichever loop runs.
+#if defined(OC_DIAGNOSTICS) || defined(OC_POLICY_MONO_LOOP)
+    constexpr bool kMono = !CONV_LDS && !FOLD && !GATHER;             // (the gather build with four digits: hipcc 7.2 crashes in 'AMDGPU Rewrite AGPR-Copy-MFMA')
+#else
+    constexpr bool kMono = false;
+#endif
     stamp(a, wave, lane, 0); stamp(a, wave, lane, 14);
 
     // conv result -> fc1 operand: relu(2^-shift x f32(sum of digit accumulators)), two accumulator registers at a time.  The channel's

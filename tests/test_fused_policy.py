@@ -365,6 +365,8 @@ def test_pipelined_position_loop_equals_the_plain_loop(W, H, digits, monkeypatch
     positions down to one and two (3x3, 4x3), every digit count, ragged last blocks, actors (argmax and sampled) and critics; and
     against the numpy restatement of the reference's f32 forward."""
     from oracle.policy_oracle import log_softmax, reference_forward
+    if not native.DIAGNOSTICS:
+        pytest.skip("the pipelined position loop is compiled into csrc/liboc_hip_diag.so (OC_DIAGNOSTICS=1) only: DESIGN.md 4.2")
     monkeypatch.setenv("OC_POLICY_COOP", "0")
     monkeypatch.setenv("OC_POLICY_DUO", "0")
     actor, critic = random_net(W, H, 6, ACTOR_HEAD, 31), random_net(W, H, 1, CRITIC_HEAD, 32)
@@ -489,6 +491,8 @@ def test_pipelined_position_loop_on_one_two_and_three_positions(monkeypatch):
     """Grids of 3x3, 4x3 and 5x3 tiles (one, two, three conv positions) through a multi-grid launch -- four-wavefront workgroups, conv
     digits in registers: the pipelined position loop's shortest cases (policy_mono_loop.h: no step at all, a last step only, one full
     step) -- against the per-grid launches, which run these small grids on the eight-wavefront build and its plain loop: bit for bit."""
+    if not native.DIAGNOSTICS:
+        pytest.skip("the pipelined position loop is compiled into csrc/liboc_hip_diag.so (OC_DIAGNOSTICS=1) only: DESIGN.md 4.2")
     monkeypatch.setenv("OC_POLICY_COOP", "0")
     from diverse_conventions_amd.fused_policy import MultiPolicyPlan
     rng = np.random.default_rng(77)
