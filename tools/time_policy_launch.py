@@ -44,7 +44,7 @@ for name, seg, nseg, rpt in shapes:
     logp = torch.zeros((rows, 6), device="cuda")
     line = f"{name:36s} {rows:7d} rows {plan.n_tiles:4d} tiles:"
     modes = [("one block, plain loop, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_MONO": "0", "OC_POLICY_COOP": "0"}), ("one block, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "0"}),
-             ("one block", {"OC_POLICY_DUO": "0"}), ("duo", {"OC_POLICY_DUO": "1"}), ("default", {})]
+             ("one block", {"OC_POLICY_DUO": "0"}), ("one block, pairs share two leftover blocks", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "2"}), ("duo", {"OC_POLICY_DUO": "1"}), ("default", {})]
     for label, env in modes:
         for k in ("OC_POLICY_DUO", "OC_POLICY_COOP", "OC_POLICY_MONO"):
             os.environ.pop(k, None)
