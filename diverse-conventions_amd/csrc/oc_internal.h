@@ -7,7 +7,8 @@
 
 // What the PRODUCT library reads from the environment: OC_NO_JIT (serve the ahead-of-time generic kernels), OC_JIT_CACHE (where
 // compiled code objects are kept), OC_DWORD_STORES (the dword-store kernels for 4-byte-aligned-only consumers' tests) and
-// OC_POLICY_COOP (0: no cooperative blocks, for plan-equality checks; documented f32-rounding effect) and OC_POLICY_DUO (0 / 1: never /
+// OC_POLICY_COOP (0: no cooperative blocks, for plan-equality checks; documented f32-rounding effect; 2: two leftover blocks of an
+// eight-wavefront stretch shared by two pairs as well -- A/B runs) and OC_POLICY_DUO (0 / 1: never /
 // wherever it fits the two-blocks-per-wavefront policy kernel; bit-identical outputs either way) -- none of them changes an
 // environment result.  Every experiment / timing knob (store modes, code-generation switches, phase ablation, traces, the folded env
 // step ...) is read through OC_DIAG_ENV, which is getenv only in the diagnostics build (-DOC_DIAGNOSTICS -> csrc/liboc_hip_diag.so,

@@ -1467,7 +1467,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
     a.coop = env_coop ? atoi(env_coop) != 0 : 1;
     a.coop2 = env_coop && atoi(env_coop) == 2 ? 2 : 0;               // (OC_POLICY_COOP=2: two leftover blocks of an eight-wavefront stretch shared by two pairs -- A/B runs; measured 1 % slower)
-    const char *const env_mono = getenv("OC_POLICY_MONO");           // (read per call) 0 = the plain position loop in the one-wavefront-per-SIMD builds: A/B runs
+    const char *const env_mono = OC_DIAG_ENV("OC_POLICY_MONO");      // (diagnostics build, read per call) 0 = the plain position loop in the one-wavefront-per-SIMD builds, 2 = timing only
     a.mono = env_mono ? atoi(env_mono) : 1;
     int grid = a.tile_per_wg ? a.n_tiles / a.tile_per_wg : n_cus;
     static const char *const env_grid = OC_DIAG_ENV("OC_POLICY_GRID");

@@ -50,7 +50,7 @@ def test_product_library_carries_no_diagnostics():
     if native.DIAGNOSTICS or native.SANITIZE or native.LIB_OVERRIDE:
         pytest.skip("not the product build")
     blob = open(native.LIB_PATH, "rb").read()
-    for needle in (b"OC_ABLATE", b"OC_FOLD", b"OC_POLICY_FOLD", b"OC_STORE_MODE", b"OC_POLICY_PLAN", b"OC_JIT_TRACE", b"OC_MIN_WAVES", b"fold_env_group",
+    for needle in (b"OC_ABLATE", b"OC_FOLD", b"OC_POLICY_FOLD", b"OC_STORE_MODE", b"OC_POLICY_PLAN", b"OC_POLICY_MONO", b"OC_JIT_TRACE", b"OC_MIN_WAVES", b"fold_env_group",
                    b"fold_expected_kernel"):
         assert needle not in blob, needle
     for kept in (b"OC_NO_JIT", b"OC_JIT_CACHE", b"OC_DWORD_STORES", b"OC_POLICY_COOP", b"OC_POLICY_DUO"):      # the documented switches of the product
