@@ -570,59 +570,79 @@ def drop_in_and_eval_legs(local, regions, gen):
     # ---- eval_1000: train/testing.py:39-59
     n, L = 1000, 200
     params = get_base_layout_params("cramped_room", L)
-    env = OvercookedMadrona("cramped_room", n, local, debug_compile=False, horizon=L)
-    dev = env.sim.device
     nets = PackedNetworks.from_state_dicts((W, H, 20), "cuda", actors=sds)
-    ego_agent = FusedVectorAgent(nets, n, [(0, n, 0)], seed=11)
-    alt_agent = FusedVectorAgent(nets, n, [(0, n, 1)], seed=12)
-    env.add_partner_agent(alt_agent)
-    rec_actions = torch.zeros((L, 2, n), dtype=torch.int32, device=dev)
-    rec_rew = torch.zeros((L, n), dtype=torch.int32, device=dev)
-    rec_done = torch.zeros((L, n), dtype=torch.int32, device=dev)
+    from diverse_conventions_amd import FusedAgentPair
 
-    def run_sim(record):
-        obs = env.reset()
-        reward = torch.zeros(n, device=dev)
-        for i in range(L):
-            action = ego_agent.get_action(obs, False)
-            obs, newreward, done, _ = env.step(action)
-            reward += newreward / 20
-            if record:
-                rec_actions[i, 0].copy_(ego_agent.actions)       # (FusedVectorAgent keeps its last actions; the env read both buffers as they were)
-                rec_actions[i, 1].copy_(alt_agent.actions)
-                rec_rew[i].copy_(newreward)
-                rec_done[i].copy_(done)
-        return reward
+    def episode_leg(make_agents):
+        """The loop as the reference writes it, with the two agents `make_agents` returns; timed over one episode, then a recorded
+        episode replayed through the CPU oracle."""
+        env = OvercookedMadrona("cramped_room", n, local, debug_compile=False, horizon=L)
+        dev = env.sim.device
+        ego_agent, alt_agent = make_agents()
+        env.add_partner_agent(alt_agent)
+        rec_actions = torch.zeros((L, 2, n), dtype=torch.int32, device=dev)
+        rec_rew = torch.zeros((L, n), dtype=torch.int32, device=dev)
+        rec_done = torch.zeros((L, n), dtype=torch.int32, device=dev)
 
-    env.sim.reset_all()
-    run_sim(False)                                                   # warm-up episode (ends exactly at the horizon: every kitchen resets)
-    torch.cuda.synchronize()
-    with regions:
-        t0 = time.perf_counter()
-        reward = run_sim(False)
+        def run_sim(record):
+            obs = env.reset()
+            reward = torch.zeros(n, device=dev)
+            for i in range(L):
+                action = ego_agent.get_action(obs, False)
+                obs, newreward, done, _ = env.step(action)
+                reward += newreward / 20
+                if record:
+                    rec_actions[i, 0].copy_(ego_agent.actions)   # (the agents keep their last actions; the env read both buffers as they were)
+                    rec_actions[i, 1].copy_(alt_agent.actions)
+                    rec_rew[i].copy_(newreward)
+                    rec_done[i].copy_(done)
+            return reward
+
+        env.sim.reset_all()
+        run_sim(False)                                               # warm-up episode (ends exactly at the horizon: every kitchen resets)
         torch.cuda.synchronize()
-        ev_s = time.perf_counter() - t0
-    start = env.sim.get_state(0, n)                                  # (the timed episode ended at the horizon too: a fresh episode starts here)
-    reward = run_sim(True)
-    torch.cuda.synchronize()
-    ora = oracle.OracleVecEnv(params, n)
-    ora.set_state(*start)
-    ok = True
-    a_all, r_all, d_all = rec_actions.cpu().numpy(), rec_rew.cpu().numpy(), rec_done.cpu().numpy()
-    total = np.zeros(n)
-    for i in range(L):
-        _, orew, odone = ora.step(np.ascontiguousarray(a_all[i]))
-        ok = ok and np.array_equal(orew[0], r_all[i]) and np.array_equal(np.asarray(odone).astype(bool), d_all[i].astype(bool))
-        total += orew[0] / 20
-    ok = ok and np.allclose(total, reward.cpu().numpy())
-    env.close()
+        with regions:
+            t0 = time.perf_counter()
+            reward = run_sim(False)
+            torch.cuda.synchronize()
+            ev_s = time.perf_counter() - t0
+        start = env.sim.get_state(0, n)                              # (the timed episode ended at the horizon too: a fresh episode starts here)
+        reward = run_sim(True)
+        torch.cuda.synchronize()
+        ora = oracle.OracleVecEnv(params, n)
+        ora.set_state(*start)
+        ok = True
+        a_all, r_all, d_all = rec_actions.cpu().numpy(), rec_rew.cpu().numpy(), rec_done.cpu().numpy()
+        total = np.zeros(n)
+        for i in range(L):
+            _, orew, odone = ora.step(np.ascontiguousarray(a_all[i]))
+            ok = ok and np.array_equal(orew[0], r_all[i]) and np.array_equal(np.asarray(odone).astype(bool), d_all[i].astype(bool))
+            total += orew[0] / 20
+        ok = ok and np.allclose(total, reward.cpu().numpy())
+        env.close()
+        return ev_s, float(reward.mean()), bool(ok)
+
+    ev_s, mean_ret, ok = episode_leg(lambda: (FusedVectorAgent(nets, n, [(0, n, 0)], seed=11), FusedVectorAgent(nets, n, [(0, n, 1)], seed=12)))
+    pair_box = []
+
+    def make_pair():
+        pair_box.append(FusedAgentPair(nets, n, [(0, n, 0)], [(0, n, 1)], seed=11))
+        return pair_box[0].ego, pair_box[0].partner
+    pair_s, pair_ret, pair_ok = episode_leg(make_pair)
+    pair_ok = pair_ok and pair_box[0].single_launches == 0 and pair_box[0].joint_launches == 3 * L
     ev = {"what": "the reference's evaluation loop (train/testing.py:39-59): cramped_room, 1000 kitchens x 200 steps, two decentralised "
                   "policies (ego and partner each one FusedVectorAgent launch per step), env.step from Python, reward / 20 accumulated",
           "kitchens": n, "steps": L, "episode_ms": ev_s * 1e3, "us_per_step": ev_s / L * 1e6, "value": 2 * n * L / ev_s, "unit": "agent-env steps/s",
-          "launches_per_step": 3, "mean_return_over_20": float(reward.mean()), "checked": bool(ok),
+          "launches_per_step": 3, "mean_return_over_20": mean_ret, "checked": bool(ok),
           "checked_note": "a third episode recorded (joint actions, rewards, dones) and replayed through the CPU oracle from the exported start "
                           "state: rewards and dones bit-identical at every step, the accumulated reward / 20 equal",
-          "note": "launch-bound: 1000 kitchens are 2 MB of planes per step; three small launches and their Python per step"}
+          "agent_pair": {"what": "the same loop, unchanged, with the two agents of a FusedAgentPair: the ego's get_action evaluates both players' "
+                                 "rows of the simulator's [2, N, ...] observation tensor in ONE policy launch and the partner's, called inside "
+                                 "env.step, hands its half out (round 6)",
+                         "episode_ms": pair_s * 1e3, "us_per_step": pair_s / L * 1e6, "value": 2 * n * L / pair_s, "launches_per_step": 2,
+                         "mean_return_over_20": pair_ret, "checked": bool(pair_ok)},
+          "note": "launch-bound: 1000 kitchens are 2 MB of planes per step; a policy launch is its fixed part (the network into LDS, one 32-row "
+                  "block per workgroup) whatever the rows"}
     return drop, ev
 
 

@@ -435,3 +435,95 @@ class FusedVectorAgent:
 
     def update(self, rewards, dones) -> None:
         pass
+
+
+class FusedAgentPair:
+    """The ego agent and the partner agent of a reference-style loop evaluated in ONE policy launch per step.
+
+    The reference's evaluation loop (train/testing.py:39-59) asks the ego for its action, then `env.step` asks the partner for its
+    own: two policy evaluations of the SAME step's observations, one after the other -- at 1000 kitchens two launches whose fixed part
+    (network into LDS, one 32-row block per workgroup) is most of a step.  `pair.ego.get_action(obs)` evaluates both players' rows
+    -- the simulator's observation tensor is `[P, N, W, H, C]`, the two players' views are its two halves -- and keeps the partner's
+    actions; `pair.partner.get_action(obs)`, called by `env.step` with the partner's view of the same step, hands them out.  Whenever
+    that is not what happens (the view handed in is not a slice of a `[2, N, ...]` tensor, the partner is asked first or twice), each
+    agent evaluates its own rows as a `FusedVectorAgent` does: same results as two separate agents with the pair's seed, one launch more.
+
+    ego_segments / partner_segments: (first kitchen, kitchens, actor net[, critic net]) as for FusedVectorAgent."""
+
+    class _Side:
+        def __init__(self, pair, side):
+            self._pair, self._side = pair, side
+
+        def get_action(self, obs, record: bool = True):
+            return self._pair._get_action(self._side, obs)
+
+        def update(self, rewards, dones) -> None:
+            pass
+
+        @property
+        def actions(self):
+            return self._pair._act[self._side]
+
+        @property
+        def action_logp(self):
+            return self._pair._alp[self._side]
+
+        @property
+        def values(self):
+            return self._pair._val[self._side] if self._pair.has_critic else None
+
+    def __init__(self, nets: PackedNetworks, n_kitchens: int, ego_segments, partner_segments, ego_ind: int = 0, deterministic: bool = False,
+                 seed: int = 0):
+        n = self.n = int(n_kitchens)
+        self.nets, self.deterministic, self.seed, self.ego_ind = nets, deterministic, seed, int(ego_ind)
+        if self.ego_ind not in (0, 1):
+            raise ValueError("two players: ego_ind is 0 or 1")
+        self.has_critic = False
+        rows = [[], []]                                      # per PLAYER (row block of the [2, N] observation tensor)
+        for side, segs in ((self.ego_ind, ego_segments), (1 - self.ego_ind, partner_segments)):
+            for seg in segs:
+                first, count, actor = int(seg[0]), int(seg[1]), int(seg[2])
+                rows[side].append((first, count, actor, TILE_ACT))
+                if len(seg) > 3 and seg[3] is not None:
+                    rows[side].append((first, count, int(seg[3]), 0))
+                    self.has_critic = True
+        self._joint = PolicyPlan(nets, 2 * n, [(p * n + f, c, k, fl) for p in (0, 1) for f, c, k, fl in rows[p]])
+        self._single = [PolicyPlan(nets, n, rows[p]) for p in (0, 1)]          # the fallback: one player's rows
+        dev = nets.device
+        self._actions = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+        self._logp = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+        self._values = torch.zeros(2 * n, dtype=torch.float32, device=dev) if self.has_critic else None
+        self._act = [self._actions[:n], self._actions[n:]]
+        self._alp = [self._logp[:n], self._logp[n:]]
+        self._val = [self._values[:n], self._values[n:]] if self.has_critic else [None, None]
+        self._ready = None                                   # player whose actions the last joint launch left to be handed out
+        self.ego, self.partner = self._Side(self, self.ego_ind), self._Side(self, 1 - self.ego_ind)
+        self.joint_launches = self.single_launches = 0
+
+    def _whole(self, side, view):
+        """The `[2, N, ...]` tensor `view` is player `side`'s half of, or None."""
+        base = view._base
+        rb = self.nets.W * self.nets.H * 20
+        if base is None or base.dtype != torch.int8 or not base.is_contiguous() or base.numel() != 2 * self.n * rb or view.numel() != self.n * rb:
+            return None
+        if not view.is_contiguous() or view.data_ptr() != base.data_ptr() + side * self.n * rb:
+            return None
+        return base
+
+    def _get_action(self, side, obs):
+        view = obs.obs
+        if self._ready == side:                              # evaluated with the other player's rows a moment ago, on this step's observations
+            self._ready = None
+            return self._act[side].view(-1, 1)
+        whole = self._whole(side, view) if side == self.ego_ind else None
+        if whole is not None:
+            self._joint.forward(whole, raw=self._values, actions=self._actions, action_logp=self._logp, deterministic=self.deterministic, seed=self.seed)
+            self._ready = 1 - side
+            self.joint_launches += 1
+        else:
+            o = view if view.is_contiguous() else view.contiguous()
+            self._single[side].forward(o, raw=self._val[side], actions=self._act[side], action_logp=self._alp[side], deterministic=self.deterministic,
+                                       seed=self.seed + 1 + side)
+            self._ready = None
+            self.single_launches += 1
+        return self._act[side].view(-1, 1)
