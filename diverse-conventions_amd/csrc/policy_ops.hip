@@ -116,6 +116,7 @@ struct PolicyArgs {
     int sample;                         // 0: argmax, 1: a draw from the distribution (inverse CDF of one counter-hash uniform per row)
     int lds_weight_bytes;               // LDS-resident part of the weight image, padded to whole KB (the copy runs in 1 KB instructions)
     int lds_wave_bytes;                 // one wavefront's row-staging area (the largest slot's)
+    int coop1;                          // eight-wavefront builds: 1 = a stretch of ONE block is shared by four wavefronts too (0: only behind full rounds)
     int coop2;                          // eight-wavefront builds: group size for TWO leftover blocks (0: not shared, the default; 2: two pairs)
     int mono;                           // one-wavefront-per-SIMD builds: the position loop pipelined inside the wavefront (policy_mono_loop.h); 0: the plain loop (OC_POLICY_MONO=0)
     int lds_flag_offset;                // eight-wavefront plans: 64 bytes of hand-shake words behind the staging areas (cooperative blocks by flags), or 0
@@ -832,9 +833,9 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     constexpr bool kCoopFlags = CONV_LDS;
     const int gsz = (!kCoopBuild || !a.coop || rem == 0 || ((flags >> 8) & 0xff) || a.lds_wave_bytes < 8192) ? 0
                     // (measured, profiles/r06_policy_coop_variants.log: two leftover blocks as two groups of four -- wavefronts 4-7 sharing the second --
-                    // cost the bench line's launch 2.7 us: the partners arrive late; a stretch without a full round -- one or two blocks in all --
-                    // is faster unshared, 11.9 against 12.6 us for 16 368 evaluations)
-                    : kCoopFlags ? ((nwaves != 8 || a.lds_flag_offset == 0 || nb_stretch < nwaves) ? 0 : rem == 1 ? 4 : rem == 2 ? a.coop2 : 0)
+                    // cost the bench line's launch 2.7 us: the partners arrive late; a stretch of two or three blocks in all is faster unshared,
+                    // 11.9 against 12.6 us for 16 368 evaluations; a stretch of ONE block is shared: 1000 evaluations 12.0 -> 11.2 us)
+                    : kCoopFlags ? ((nwaves != 8 || a.lds_flag_offset == 0 || (nb_stretch < nwaves && nb_stretch != a.coop1)) ? 0 : rem == 1 ? 4 : rem == 2 ? a.coop2 : 0)
                     : nwaves != 4 ? 0 : rem == 1 ? 4 : rem == 2 ? 2 : 0;
     const bool coop = gsz > 0 && P >= gsz;
     coop_seq += coop ? 1 : 0;
@@ -1466,6 +1467,7 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     a.desync = env_desync ? atoi(env_desync) : 0;
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
     a.coop = env_coop ? atoi(env_coop) != 0 : 1;
+    a.coop1 = env_coop && atoi(env_coop) == 4 ? 0 : 1;               // (OC_POLICY_COOP=4: a one-block stretch stays on one wavefront -- A/B runs)
     a.coop2 = env_coop && atoi(env_coop) == 2 ? 2 : 0;               // (OC_POLICY_COOP=2: two leftover blocks of an eight-wavefront stretch shared by two pairs -- A/B runs; measured 1 % slower)
     const char *const env_mono = OC_DIAG_ENV("OC_POLICY_MONO");      // (diagnostics build, read per call) 0 = the plain position loop in the one-wavefront-per-SIMD builds, 2 = timing only
     a.mono = env_mono ? atoi(env_mono) : 1;

@@ -347,8 +347,8 @@ def test_cooperative_blocks(W, H, blocks, monkeypatch):
         assert np.array_equal(a["actions"][clear], want_lp.argmax(1)[clear]) and (a["actions"] >= 0).all()
     (a1, v1), (a0, v0) = got["1"], got["0"]
     assert np.abs(a1["logp"] - a0["logp"]).max() < 2e-6 * scale and np.abs(v1 - v0).max() < 2e-6 * scale
-    shared = (blocks % 8 == 1 and blocks > 8) if (W, H) == (5, 4) else blocks % 4 in (1, 2) and (W - 2) * (H - 2) >= 4
-    if (W, H) == (5, 4) and not shared:                             # (eight wavefronts: only a stretch's 8 k + 1st block, k >= 1, is shared)
+    shared = blocks % 8 == 1 if (W, H) == (5, 4) else blocks % 4 in (1, 2) and (W - 2) * (H - 2) >= 4
+    if (W, H) == (5, 4) and not shared:                             # (eight wavefronts: only a stretch's 8 k + 1st block is shared)
         assert np.array_equal(a1["logp"], a0["logp"]) and np.array_equal(v1, v0)
         return
     assert shared and not (np.array_equal(a1["logp"], a0["logp"]) and np.array_equal(v1, v0))

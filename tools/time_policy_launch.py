@@ -33,7 +33,7 @@ def timed(fn, iters=100, batches=7):
     return min(out), float(np.median(out))
 
 
-shapes = [("32 x 4096 (16 blocks per workgroup)", 4096, 32, None), ("15 x 4369 x 2 sides (bench line)", 4369, 30, None), ("15 x 4352 x 2", 4352, 30, None), ("245 760 rows, 1024 per tile", 61440, 4, 1024),
+shapes = [("2 x 1000 (eval_1000, both agents)", 1000, 2, None), ("1 x 1000 (eval_1000, one agent)", 1000, 1, None), ("32 x 4096 (16 blocks per workgroup)", 4096, 32, None), ("15 x 4369 x 2 sides (bench line)", 4369, 30, None), ("15 x 4352 x 2", 4352, 30, None), ("245 760 rows, 1024 per tile", 61440, 4, 1024),
           ("8184 x 2 (config 4 share)", 264, 62, None)]
 ref = {}
 for name, seg, nseg, rpt in shapes:
@@ -44,7 +44,7 @@ for name, seg, nseg, rpt in shapes:
     logp = torch.zeros((rows, 6), device="cuda")
     line = f"{name:36s} {rows:7d} rows {plan.n_tiles:4d} tiles:"
     modes = [("one block, plain loop, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_MONO": "0", "OC_POLICY_COOP": "0"}), ("one block, no coop", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "0"}),
-             ("one block", {"OC_POLICY_DUO": "0"}), ("one block, pairs share two leftover blocks", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "2"}), ("duo", {"OC_POLICY_DUO": "1"}), ("default", {})]
+             ("one block", {"OC_POLICY_DUO": "0"}), ("one block, single blocks unshared", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "4"}), ("one block, pairs share two leftover blocks", {"OC_POLICY_DUO": "0", "OC_POLICY_COOP": "2"}), ("duo", {"OC_POLICY_DUO": "1"}), ("default", {})]
     for label, env in modes:
         for k in ("OC_POLICY_DUO", "OC_POLICY_COOP", "OC_POLICY_MONO"):
             os.environ.pop(k, None)
