@@ -1462,7 +1462,9 @@ int launch_policy(PolicyArgs &a, int digits, bool multi, int32_t cu_budget, hipS
     // workgroup i runs tile i.  A shorter table (e.g. one entry per segment) is split evenly, block by block.
     // (more tiles than CUs -- many segments on a small CU share -- would need a second round of workgroups: split evenly instead)
     // Several grids: workgroup i owns tile_per_wg consecutive entries of the table (oc_policy_plan_tiles_multi).
-    if (!multi) a.tile_per_wg = (a.n_tiles >= n_cus / 2 && a.n_tiles <= n_cus) ? 1 : 0;
+    // (a small launch -- at least as many tiles as the rows have blocks, e.g. the 32 one-block tiles the planner cuts 1000 rows into -- is
+    // mapped the same way: 32 workgroups instead of 256 that each scan the table to find out they have nothing to do)
+    if (!multi) a.tile_per_wg = (a.n_tiles <= n_cus && (a.n_tiles >= n_cus / 2 || (s0.n_rows + kRowsPerBlock - 1) / kRowsPerBlock <= a.n_tiles)) ? 1 : 0;
     static const char *const env_desync = OC_DIAG_ENV("OC_POLICY_DESYNC");
     a.desync = env_desync ? atoi(env_desync) : 0;
     const char *const env_coop = getenv("OC_POLICY_COOP");           // diagnostics (read per call): 0 = every block on one wavefront
