@@ -630,6 +630,25 @@ def drop_in_and_eval_legs(local, regions, gen):
         return pair_box[0].ego, pair_box[0].partner
     pair_s, pair_ret, pair_ok = episode_leg(make_pair)
     pair_ok = pair_ok and pair_box[0].single_launches == 0 and pair_box[0].joint_launches == 3 * L
+    # the same evaluation with the loop handed to the library: FusedPairedRollout over ONE segment (ego = network 0, partner = network 1),
+    # the episode's 200 steps -- one policy launch + one env launch each -- enqueued by one call into a trajectory, reward / 20 summed once
+    from diverse_conventions_amd import FusedPairedRollout, OvercookedEngine, TrajectoryBuffer
+    eng_l = OvercookedEngine(params, n, local)
+    ro_l = FusedPairedRollout(eng_l, nets, n, 0, actor_nets=[[0], [1]], seed=11)
+    traj_l = TrajectoryBuffer(eng_l, L)
+    ro_l.collect(traj_l)                                             # warm-up episode (ends at the horizon: every kitchen resets)
+    traj_l.after_update()
+    torch.cuda.synchronize()
+    with regions:
+        t0 = time.perf_counter()
+        ro_l.collect(traj_l)
+        lib_ret = traj_l.reward[:, 0].sum(0) / 20
+        torch.cuda.synchronize()
+        lib_s = time.perf_counter() - t0
+    traj_l.after_update()
+    lib_ok = check_policy_in_loop(ro_l, eng_l, params, blocks=3, per_block=48)
+    lib_mean = float(lib_ret.float().mean())
+    eng_l.close()
     ev = {"what": "the reference's evaluation loop (train/testing.py:39-59): cramped_room, 1000 kitchens x 200 steps, two decentralised "
                   "policies (ego and partner each one FusedVectorAgent launch per step), env.step from Python, reward / 20 accumulated",
           "kitchens": n, "steps": L, "episode_ms": ev_s * 1e3, "us_per_step": ev_s / L * 1e6, "value": 2 * n * L / ev_s, "unit": "agent-env steps/s",
@@ -641,6 +660,11 @@ def drop_in_and_eval_legs(local, regions, gen):
                                  "env.step, hands its half out (round 6)",
                          "episode_ms": pair_s * 1e3, "us_per_step": pair_s / L * 1e6, "value": 2 * n * L / pair_s, "launches_per_step": 2,
                          "mean_return_over_20": pair_ret, "checked": bool(pair_ok)},
+          "library_loop": {"what": "the same evaluation with the loop handed to the library (FusedPairedRollout, one segment: ego network 0, "
+                                   "partner network 1): 200 x (one policy launch + one env launch) enqueued by ONE call into a time-major "
+                                   "trajectory, reward / 20 summed at the end",
+                           "episode_ms": lib_s * 1e3, "us_per_step": lib_s / L * 1e6, "value": 2 * n * L / lib_s, "launches_per_step": 2,
+                           "mean_return_over_20": lib_mean, "checked": bool(lib_ok)},
           "note": "launch-bound: 1000 kitchens are 2 MB of planes per step; a policy launch is its fixed part (the network into LDS, one 32-row "
                   "block per workgroup) whatever the rows"}
     return drop, ev
