@@ -117,24 +117,25 @@ def test_fused_partner_agent_in_the_reference_loop(layout_params):
     env.close()
 
 
-def test_agent_pair_evaluates_both_players_in_one_launch(layout_params):
+@pytest.mark.parametrize("ego_ind", [0, 1])
+def test_agent_pair_evaluates_both_players_in_one_launch(layout_params, ego_ind):
     """FusedAgentPair in the reference's evaluation loop (train/testing.py:39-59: ego.get_action, then env.step asks the partner): ONE
     policy launch per step over both players' halves of the simulator's observation tensor -- same actions, log-probabilities and
     values as two FusedVectorAgents in a second environment driven side by side (deterministic policies), the env against the oracle;
     and the fallbacks: an observation that is no view of the [2, N, ...] tensor, the partner asked first."""
     import os
     from conftest import GOLDEN
-    from diverse_conventions_amd import FusedAgentPair, FusedVectorAgent, PackedNetworks, VectorObservation, generate_env
+    from diverse_conventions_amd import FusedAgentPair, FusedVectorAgent, OvercookedMadrona, PackedNetworks, VectorObservation
     z = np.load(os.path.join(GOLDEN, "policy_cases.npz"))
     pick = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and ("weight" in k or "bias" in k)}
     nets = PackedNetworks.from_state_dicts((5, 4, 20), "cuda", actors=[pick(f"a{i}.") for i in range(3)], critics=[pick("c0.")])
     n, T = 333, 40
     ego_segs, alt_segs = [(0, 200, 0, 3), (200, 133, 1, 3)], [(0, n, 2, 3)]
-    env_a, env_b = generate_env("overcooked", n, "simple"), generate_env("overcooked", n, "simple")
-    pair = FusedAgentPair(nets, n, ego_segs, alt_segs, deterministic=True)
-    env_a.add_partner_agent(pair.partner)
+    env_a, env_b = (OvercookedMadrona("simple", n, 0, debug_compile=False, ego_agent_idx=ego_ind) for _ in range(2))
+    pair = FusedAgentPair(nets, n, ego_segs, alt_segs, ego_ind=ego_ind, deterministic=True)
+    env_a.add_partner_agent(pair.partner, player_num=1 - ego_ind)
     ego_b, alt_b = FusedVectorAgent(nets, n, ego_segs, deterministic=True), FusedVectorAgent(nets, n, alt_segs, deterministic=True)
-    env_b.add_partner_agent(alt_b)
+    env_b.add_partner_agent(alt_b, player_num=1 - ego_ind)
     ora = oracle.OracleVecEnv(layout_params["simple"], n)
     oa, ob = env_a.reset(), env_b.reset()
     for t in range(T):
@@ -146,15 +147,16 @@ def test_agent_pair_evaluates_both_players_in_one_launch(layout_params):
         assert torch.equal(pair.partner.actions, alt_b.actions) and torch.equal(pair.partner.action_logp, alt_b.action_logp), t
         assert torch.equal(pair.ego.values, ego_b.values) and torch.equal(pair.partner.values, alt_b.values), t
         assert torch.equal(oa.obs, ob.obs) and torch.equal(ra, rb) and torch.equal(da, db), t
-        oobs, orew, odone = ora.step(np.stack([a[:, 0].cpu().numpy(), pair.partner.actions.cpu().numpy()]))
-        assert np.array_equal(oa.obs.cpu().numpy(), oobs[0]) and np.array_equal(ra.cpu().numpy(), orew[0]), t
+        joint = [a[:, 0].cpu().numpy(), pair.partner.actions.cpu().numpy()]
+        oobs, orew, odone = ora.step(np.stack(joint if ego_ind == 0 else joint[::-1]))
+        assert np.array_equal(oa.obs.cpu().numpy(), oobs[ego_ind]) and np.array_equal(ra.cpu().numpy(), orew[ego_ind]), t
     assert pair.joint_launches == T and pair.single_launches == 0
     # fallbacks: a copy of the ego's view (no view of the whole tensor) -> the ego's rows alone, then the partner's alone; the partner first
     copy = VectorObservation(oa.active, oa.obs.clone(), action_mask=oa.action_mask)
     a1 = pair.ego.get_action(copy).clone()
     assert pair.single_launches == 1 and torch.equal(a1, ego_b.get_action(ob))
-    p1 = pair.partner.get_action(env_a._obs[1]).clone()
-    assert pair.single_launches == 2 and torch.equal(p1, alt_b.get_action(env_b._obs[1]))
+    p1 = pair.partner.get_action(env_a._obs[1 - ego_ind]).clone()
+    assert pair.single_launches == 2 and torch.equal(p1, alt_b.get_action(env_b._obs[1 - ego_ind]))
     env_a.close(); env_b.close()
 
 
