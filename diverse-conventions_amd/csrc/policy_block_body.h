@@ -60,7 +60,7 @@
         // later, so nothing waits for them), and the LDS reads for position p+2 are in flight.
         // (a cooperative block: this wavefront's positions are [p_first, p_end), the leader's run shorter by about the dense tail it
         // runs alone afterwards -- coop_lead positions, see the kernel; otherwise all of them)
-        const int coop_rest = P - coop_lead, coop_each = cp ? coop_rest / (gsz - 1) : 0, coop_more = cp ? coop_rest - coop_each * (gsz - 1) : 0;
+        const int coop_rest = P - coop_lead, coop_each = cp ? (gsz == 2 ? coop_rest : (coop_rest * 21846) >> 16) : 0,     /* coop_rest / (gsz - 1), gsz - 1 = 1 or 3 (exact below 16 384) */ coop_more = cp ? coop_rest - coop_each * (gsz - 1) : 0;
         const int p_first = !cp ? 0 : member == 0 ? 0 : coop_lead + (member - 1) * coop_each + min(member - 1, coop_more);
         const int p_end = !cp ? P : member == 0 ? coop_lead : p_first + coop_each + (member - 1 < coop_more ? 1 : 0);
         v16f h1[2];                                                   // accumulators start at the bias (a cooperative block: the leader's do)

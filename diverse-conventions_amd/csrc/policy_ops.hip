@@ -822,7 +822,7 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     // (a run of consecutive positions each), accumulate partial fc1 sums over their positions from the group leader's staged rows, and hand
     // them to the leader through their own (idle) staging areas; the leader adds them up and runs the dense tail alone.  Three
     // workgroup barriers per stretch, only here; every wavefront of the workgroup passes them.
-    const int nb_stretch = last - first, rem = nb_stretch % nwaves;
+    const int nb_stretch = last - first, rem = nb_stretch & (nwaves - 1);   // (a workgroup is 1, 4 or 8 wavefronts: no runtime division in the prologue)
     // (only in the builds that run one wavefront per SIMD -- conv digits in registers -- and not in the gather build, which is at its
     // register limit without a second block body.  Two wavefronts per SIMD, measured: the barrier in front of the shared block waits
     // for the slowest of eight drifting wavefronts, which costs more than the block -- 52.4 against 48.6 us for the bench line's launch)
@@ -841,9 +841,10 @@ __global__ __launch_bounds__(CONV_LDS ? 512 : 256) void oc_policy_kernel(const i
     coop_seq += coop ? 1 : 0;
     // the leader also runs fc2, head and the epilogue -- about three positions' worth of time -- while the others are already idle:
     // its run of positions is shorter by that much (L + 3 = (P - L) / (g - 1)), one position at least
-    const int coop_lead = coop ? min(max((P - kCoopTailPositions * (gsz - 1)) / gsz, 1), P - (gsz - 1)) : 0;
+    const int gshift = gsz == 4 ? 2 : 1;                              // (gsz is 2 or 4: x / gsz as a shift; a negative numerator ends at the max below either way)
+    const int coop_lead = coop ? min(max((P - kCoopTailPositions * (gsz - 1)) >> gshift, 1), P - (gsz - 1)) : 0;
     const int last_full = coop ? last - rem : last;                   // blocks [first, last_full): one wavefront each
-    const int grp = coop ? wave / gsz : 0, member = coop ? wave - grp * gsz : 0;
+    const int grp = coop ? wave >> gshift : 0, member = coop ? wave - grp * gsz : 0;
     const bool in_coop = coop && grp < rem, leader = in_coop && member == 0;
     const int first_item = first + wave < last_full ? first + wave : leader ? last_full + grp : -1;
     const bool have_rows = first_item >= 0;
