@@ -496,7 +496,7 @@ class FusedAgentPair:
         self._act = [self._actions[:n], self._actions[n:]]
         self._alp = [self._logp[:n], self._logp[n:]]
         self._val = [self._values[:n], self._values[n:]] if self.has_critic else [None, None]
-        self._ready = None                                   # player whose actions the last joint launch left to be handed out
+        self._ready, self._ready_ptr = None, 0               # player whose actions the last joint launch left to be handed out, and of which tensor
         self.ego, self.partner = self._Side(self, self.ego_ind), self._Side(self, 1 - self.ego_ind)
         self.joint_launches = self.single_launches = 0
 
@@ -514,11 +514,13 @@ class FusedAgentPair:
         view = obs.obs
         if self._ready == side:                              # evaluated with the other player's rows a moment ago, on this step's observations
             self._ready = None
-            return self._act[side].view(-1, 1)
+            w = self._whole(side, view)
+            if w is not None and w.data_ptr() == self._ready_ptr:   # (the same simulator's tensor: not another env's view)
+                return self._act[side].view(-1, 1)
         whole = self._whole(side, view) if side == self.ego_ind else None
         if whole is not None:
             self._joint.forward(whole, raw=self._values, actions=self._actions, action_logp=self._logp, deterministic=self.deterministic, seed=self.seed)
-            self._ready = 1 - side
+            self._ready, self._ready_ptr = 1 - side, whole.data_ptr()
             self.joint_launches += 1
         else:
             o = view if view.is_contiguous() else view.contiguous()
